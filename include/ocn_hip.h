@@ -1,0 +1,117 @@
+/*
+ * ocn_hip.h — C ABI of libocn_hip.so, the MI355X (gfx950) implementation of OCN's
+ * common-neighbour predictor hot path.
+ *
+ * The reference (qingpingmo/OCN) is pure Python: the boundary of this path is a Python
+ * module API, and every entry below replaces the third-party native call
+ * the reference makes at the cited file:line (paths relative to the reference root).
+ * The Python mirror in ocn_amd/ binds these with ctypes.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller; nothing is allocated or freed
+ *    inside the library and no entry synchronises the host (graph-capturable);
+ *  - `stream` is a hipStream_t passed as void*; work is enqueued on it and the call returns;
+ *  - CSR adjacency: rowptr int64 [n_rows+1], col int32 [nnz], columns ascending in a row;
+ *  - candidate edges: int64 src[B], dst[B] (the reference's LongTensor tar_ei rows);
+ *  - return value: 0 on success, a positive hipError_t from the launch, or a negative
+ *    OCN_E* code for argument errors.  Never throws.
+ */
+#ifndef OCN_HIP_H
+#define OCN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCN_ABI_VERSION 1
+#define OCN_EINVAL (-1)   /* null pointer / negative size / unsupported combination */
+#define OCN_ECAP   (-2)   /* reported through the device status word: flags capacity too small */
+
+/* bits of a CN flag byte */
+#define OCN_F_CN1 1u      /* neighbour k of src is in adj1-target row of dst  (cn1 entry) */
+#define OCN_F_CN2 2u      /* neighbour k of src is in adj2-target row of dst  (cn2 entry) */
+
+int ocn_abi_version(void);
+
+/* Scratch bytes the scan entries need for `n` items. */
+int64_t ocn_scan_workspace_bytes(int64_t n);
+
+/* off[e] = sum_{e'<e} deg_A(src[e']), off[B] = total: where each batch row starts in the
+ * flag buffer.  Replaces the row bookkeeping of SparseTensor.__getitem__ (utils.py:256). */
+int ocn_edge_offsets(const int64_t* rowptrA, const int64_t* src, int64_t B,
+                     int64_t* off, void* workspace, void* stream);
+
+/* Exclusive scan of int32 counts into int64 offsets (out[n] = total). */
+int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, void* stream);
+
+/* The intersection: utils.adjoverlap -> spmoverlap_ (utils.py:162-183, 248-285), both calls
+ * of a batch fused.  For edge e=(i,j) and the p-th neighbour k of i in A:
+ *   flags[off[e]+p] = [k in T1 row j] | [k in T2 row j] << 1
+ * cnt1[e] / cnt2[e] = |cn1_e| / |cn2_e| (the integer CN counts), and the per-column
+ * histograms hist[k] = {n1, n2, n_union, 0} are accumulated (cn.sum(dim=0), model.py:2261,
+ * 3114; must be zero on entry).  T2 may be NULL (single adjoverlap call).
+ * status: device int32, bit 0 set if off[B] > flags_cap (nothing is written past the cap). */
+int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA,
+                 const int64_t* rowptrT1, const int32_t* colT1,
+                 const int64_t* rowptrT2, const int32_t* colT2,
+                 const int64_t* src, const int64_t* dst, int64_t B,
+                 const int64_t* off, uint8_t* flags, int64_t flags_cap,
+                 int32_t* hist /* [N][4] */, int32_t* cnt1, int32_t* cnt2,
+                 int32_t* status, void* stream);
+
+/* Per-column weights, written IN PLACE over hist (int32[N][4] -> float[N][4]) as
+ *   {w1, w2_both, w2_only2, w2_only1}:
+ * cn5 (model.py:2261-2272, 2352-2413): w1 = 1/S1 (0 if S1 < 2); scale = max w1 over cn1
+ * entries; nip = innerprod/scale (scale>0); v = cn2 - nip*ncn1 on the union pattern;
+ * S2 = column sums of v (0 -> 1); w2_* = v_* / S2.  `innerprod` is a device float[1] (the
+ * module buffer); `scalars` is a device scratch of 4 int32, zero on entry.
+ * cn7 (model.py:3114-3126, 3186-3209): w1 = 1/S1, `sum_fill` where S1 < 2; cn2 raw ->
+ * {w1, 1, 1, 0}. */
+int ocn_cn_weights_cn5(int32_t* hist, int64_t N, const float* innerprod, int32_t* scalars,
+                       void* stream);
+int ocn_cn_weights_cn7(int32_t* hist, int64_t N, float sum_fill, void* stream);
+
+/* The pooling: spmm_add(ncn1, x), spmm_add(ncn2, x) and x[i]*x[j] (model.py:2426-2429,
+ * 3213-3216) in one pass.  xcn1[e] = sum_{k in cn1_e} w1[k] h[k]; xcn2[e] = sum over the
+ * union pattern of w2_type[k] h[k]; xij[e] = h[i] (.) h[j]; entries in ascending column
+ * order, fp32 multiply then add.  h is [N][H] row-major fp32; outputs [B][H]. */
+int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA,
+                  const int64_t* src, const int64_t* dst, int64_t B,
+                  const int64_t* off, const uint8_t* flags, const float* weights /* [N][4] */,
+                  const float* h, int32_t H,
+                  float* xcn1, float* xcn2, float* xij, void* stream);
+
+/* CSR SpMM of the encoders: torch_sparse spmm_add/mean/max (model.py:42-55), PyG GCNConv
+ * propagate (model.py:58-68), pygho/torch COO @ dense (model.py:105-113).
+ *   y[r] = post[r] * reduce_k( pre[r]^a * pre[k] * x[k] )  (+ self term)
+ * pre/post may be NULL (= 1).  mode: 0 sum, 1 mean, 2 max.
+ * edge_scale: 0 -> entry weight is pre[k] applied to x[k] first (PureConv: n*x then A.);
+ *             1 -> entry weight is fl(pre[r]*pre[k]) (GCNConv / PureConv2: normalised A).
+ * self_mode: 0 none; 1 add the row's own term after the neighbours (PureConv gcn);
+ *            2 insert it at its sorted column position (GCNConv fill_diag). */
+int ocn_spmm_csr(const int64_t* rowptr, const int32_t* col, int64_t n_rows,
+                 const float* x, int32_t F, const float* pre, const float* post,
+                 int32_t mode, int32_t edge_scale, int32_t self_mode,
+                 float* y, void* stream);
+
+/* out[r] = 1/sqrt(add + deg(r)) (0 where the argument is 0): rsqrt_(1+adj.sum(-1)) of
+ * model.py:51,106 (add=1) and gcn_norm's deg^-1/2 (add=1 after fill_diag). */
+int ocn_deg_rsqrt(const int64_t* rowptr, int64_t n_rows, float add, float* out, void* stream);
+
+/* Pattern of A*A (NeighborOverlap_large.py:68-74,112-119: spadj @ spadj, values dropped).
+ * Two phases around a caller-side allocation: count -> ocn_scan_i32 -> fill.
+ * Needs n_cols <= ocn_spgemm_max_cols().  Output columns ascending per row. */
+int64_t ocn_spgemm_max_cols(void);
+int ocn_spgemm_pattern_count(const int64_t* rowptrA, const int32_t* colA, int64_t n_rows,
+                             const int64_t* rowptrB, const int32_t* colB, int64_t n_colsB,
+                             int32_t* row_count, void* stream);
+int ocn_spgemm_pattern_fill(const int64_t* rowptrA, const int32_t* colA, int64_t n_rows,
+                            const int64_t* rowptrB, const int32_t* colB, int64_t n_colsB,
+                            const int64_t* rowptrC, int32_t* colC, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCN_HIP_H */

@@ -1,0 +1,91 @@
+"""ctypes binding of libocn_hip.so (include/ocn_hip.h).
+
+The product path has NO fallback: if the shared library is missing or an entry returns a
+non-zero status, this raises.  ``build()`` compiles it in-tree with hipcc for gfx950.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_float, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libocn_hip.so")
+SRC = os.path.join(_HERE, "csrc", "ocn_kernels.hip")
+INCLUDE = os.path.join(_ROOT, "include")
+
+# name -> (restype, argtypes); must list every symbol include/ocn_hip.h declares
+_P = c_void_p
+SIGNATURES = {
+    "ocn_abi_version": (c_int32, []),
+    "ocn_scan_workspace_bytes": (c_int64, [c_int64]),
+    "ocn_edge_offsets": (c_int32, [_P, _P, c_int64, _P, _P, _P]),
+    "ocn_scan_i32": (c_int32, [_P, c_int64, _P, _P, _P]),
+    "ocn_cn_flags": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P]),
+    "ocn_cn_weights_cn5": (c_int32, [_P, c_int64, _P, _P, _P]),
+    "ocn_cn_weights_cn7": (c_int32, [_P, c_int64, c_float, _P]),
+    "ocn_cn_gather": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int32, _P, _P, _P, _P]),
+    "ocn_spmm_csr": (c_int32, [_P, _P, c_int64, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
+    "ocn_deg_rsqrt": (c_int32, [_P, c_int64, c_float, _P, _P]),
+    "ocn_spgemm_max_cols": (c_int64, []),
+    "ocn_spgemm_pattern_count": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P]),
+    "ocn_spgemm_pattern_fill": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, _P]),
+}
+
+
+class OcnHipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/ocn_kernels.hip -> ocn_amd/libocn_hip.so for gfx950 (hipcc cross-compiles
+    without a GPU)."""
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
+            os.path.getmtime(SRC), os.path.getmtime(os.path.join(INCLUDE, "ocn_hip.h"))):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
+           f"-I{INCLUDE}", "-o", LIB_PATH, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OcnHipError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "ocn_amd has no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if l.ocn_abi_version() != 1:
+            raise OcnHipError("libocn_hip.so ABI version mismatch")
+        _lib = l
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise OcnHipError(f"{what} failed with status {status}"
+                          + (" (invalid argument)" if status == -1 else ""))
+
+
+def ptr(t) -> c_void_p:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream_ptr() -> c_void_p:
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

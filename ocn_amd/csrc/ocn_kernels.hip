@@ -1,0 +1,801 @@
+// libocn_hip.so — gfx950 (MI355X / CDNA4) kernels for OCN's common-neighbour predictor path.
+// C ABI declared in include/ocn_hip.h (which cites the reference call sites each entry replaces).
+//
+// Everything here is HBM/L2-bound integer + fp32 gather work: wave64 ballot / shuffle idioms,
+// coalesced CSR row loads, 16-byte row gathers, LDS bitmaps.  No MFMA on purpose.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ocn_hip.h"
+
+#define OCN_WAVE 64
+#define OCN_BLOCK 256
+#define OCN_WPB (OCN_BLOCK / OCN_WAVE)
+
+typedef long long i64;
+
+static inline int launch_status() { return (int)hipGetLastError(); }
+
+static inline int grid_for(i64 items_per_block_units, i64 cap = (1 << 20)) {
+  i64 g = items_per_block_units < 1 ? 1 : items_per_block_units;
+  return (int)(g > cap ? cap : g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave / block primitives
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, OCN_WAVE);
+  return v;
+}
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ i64 wave_incl_scan(i64 v, int lane) {
+#pragma unroll
+  for (int o = 1; o < OCN_WAVE; o <<= 1) {
+    i64 t = __shfl_up(v, o, OCN_WAVE);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns the thread's prefix and
+// the block total.  `sh` is 2*OCN_WPB i64 of LDS.
+__device__ __forceinline__ i64 block_excl_scan(i64 v, i64* sh, i64* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  i64 inc = wave_incl_scan(v, lane);
+  if (lane == 63) sh[w] = inc;
+  __syncthreads();
+  i64 base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < OCN_WPB; ++i) {
+    i64 s = sh[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scans (edge offsets, row offsets)
+// ---------------------------------------------------------------------------------------------
+#define SCAN_IPT 8
+#define SCAN_TILE (OCN_BLOCK * SCAN_IPT)
+
+struct DegOfSrc {
+  const i64* rowptr;
+  const i64* src;
+  __device__ __forceinline__ i64 operator()(i64 e) const {
+    i64 i = src[e];
+    return rowptr[i + 1] - rowptr[i];
+  }
+};
+struct I32In {
+  const int32_t* in;
+  __device__ __forceinline__ i64 operator()(i64 e) const { return (i64)in[e]; }
+};
+
+template <typename Op>
+__global__ __launch_bounds__(OCN_BLOCK) void scan_tile_sums(Op op, i64 n, i64* tile_sum) {
+  __shared__ i64 sh[OCN_WPB];
+  const i64 base = (i64)blockIdx.x * SCAN_TILE;
+  i64 s = 0;
+#pragma unroll
+  for (int t = 0; t < SCAN_IPT; ++t) {
+    i64 e = base + (i64)t * OCN_BLOCK + threadIdx.x;
+    if (e < n) s += op(e);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    i64 t = 0;
+    for (int i = 0; i < OCN_WPB; ++i) t += sh[i];
+    tile_sum[blockIdx.x] = t;
+  }
+}
+
+// one block: exclusive scan of tile_sum[0..nt) in place, tile_sum[nt] = total
+__global__ __launch_bounds__(OCN_BLOCK) void scan_spine(i64* tile_sum, i64 nt) {
+  __shared__ i64 sh[2 * OCN_WPB];
+  i64 carry = 0;
+  for (i64 c0 = 0; c0 < nt; c0 += OCN_BLOCK) {
+    i64 idx = c0 + threadIdx.x;
+    i64 v = idx < nt ? tile_sum[idx] : 0;
+    i64 tot;
+    i64 ex = block_excl_scan(v, sh, &tot);
+    if (idx < nt) tile_sum[idx] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) tile_sum[nt] = carry;
+}
+
+template <typename Op>
+__global__ __launch_bounds__(OCN_BLOCK) void scan_apply(Op op, i64 n, const i64* tile_sum, i64 nt,
+                                                        i64* out) {
+  __shared__ i64 sh[2 * OCN_WPB];
+  // thread-contiguous items so that the prefix order is the item order
+  const i64 base = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_IPT;
+  i64 v[SCAN_IPT];
+  i64 s = 0;
+#pragma unroll
+  for (int t = 0; t < SCAN_IPT; ++t) {
+    i64 e = base + t;
+    v[t] = e < n ? op(e) : 0;
+    s += v[t];
+  }
+  i64 tot;
+  i64 ex = block_excl_scan(s, sh, &tot) + tile_sum[blockIdx.x];
+#pragma unroll
+  for (int t = 0; t < SCAN_IPT; ++t) {
+    i64 e = base + t;
+    if (e < n) out[e] = ex;
+    ex += v[t];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_sum[nt];
+}
+
+template <typename Op>
+static int run_scan(Op op, i64 n, i64* out, void* ws, hipStream_t st) {
+  if (n < 0 || !out || !ws) return OCN_EINVAL;
+  i64 nt = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nt == 0) nt = 1;
+  i64* tile_sum = (i64*)ws;
+  hipLaunchKernelGGL(scan_tile_sums<Op>, dim3((unsigned)nt), dim3(OCN_BLOCK), 0, st, op, n, tile_sum);
+  hipLaunchKernelGGL(scan_spine, dim3(1), dim3(OCN_BLOCK), 0, st, tile_sum, nt);
+  hipLaunchKernelGGL(scan_apply<Op>, dim3((unsigned)nt), dim3(OCN_BLOCK), 0, st, op, n, tile_sum, nt, out);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: per-edge neighbour-set intersection -> flag bytes, CN counts, column histograms
+// ---------------------------------------------------------------------------------------------
+// Membership of `key` in the ascending list a[0..n): branch-uniform binary search (every lane of
+// the wave searches the same row, so the trip count is wave-uniform and the top levels of the
+// search tree are shared cache lines).
+__device__ __forceinline__ bool sorted_has(const int32_t* __restrict__ a, i64 n, int32_t key) {
+  i64 lo = 0, hi = n;
+  bool found = false;
+  while (lo < hi) {
+    i64 mid = (lo + hi) >> 1;
+    int32_t v = a[mid];
+    found |= (v == key);
+    if (v < key) lo = mid + 1; else hi = mid;
+  }
+  return found;
+}
+
+template <bool HAS_T2>
+__global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ rowptrT1, const int32_t* __restrict__ colT1,
+    const i64* __restrict__ rowptrT2, const int32_t* __restrict__ colT2,
+    const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
+    const i64* __restrict__ off, uint8_t* __restrict__ flags, i64 cap,
+    int32_t* __restrict__ hist, int32_t* __restrict__ cnt1, int32_t* __restrict__ cnt2,
+    int32_t* __restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const i64 wave0 = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6);
+  const i64 nwaves = (i64)gridDim.x * OCN_WPB;
+  if (wave0 == 0 && lane == 0 && off[B] > cap) atomicOr(status, 1);
+  for (i64 e = wave0; e < B; e += nwaves) {
+    const i64 i = src[e], j = dst[e];
+    const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+    const i64 b0 = rowptrT1[j], db = rowptrT1[j + 1] - b0;
+    i64 c0 = 0, dc = 0;
+    if (HAS_T2) { c0 = rowptrT2[j]; dc = rowptrT2[j + 1] - c0; }
+    const i64 base = off[e];
+    const bool fits = base + da <= cap;
+    int c1 = 0, c2 = 0;
+    for (i64 p = lane; p < da; p += OCN_WAVE) {
+      const int32_t k = colA[a0 + p];
+      const bool f1 = sorted_has(colT1 + b0, db, k);
+      const bool f2 = HAS_T2 ? sorted_has(colT2 + c0, dc, k) : false;
+      if (fits) flags[base + p] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
+      if (f1 | f2) {
+        int32_t* hk = hist + 4 * (i64)k;
+        if (f1) atomicAdd(hk + 0, 1);
+        if (f2) atomicAdd(hk + 1, 1);
+        atomicAdd(hk + 2, 1);
+      }
+      c1 += f1;
+      c2 += f2;
+    }
+    c1 = wave_sum(c1);
+    c2 = wave_sum(c2);
+    if (lane == 0) {
+      cnt1[e] = c1;
+      if (cnt2) cnt2[e] = c2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: per-column weights, in place over the histogram
+// ---------------------------------------------------------------------------------------------
+// scalars[0] = min{n1 : n1 >= 2} (INT_MAX if none), scalars[1] = any cn1 entry, scalars[2] = any
+// union entry.  Caller zeroes them; slot 0 is re-based with atomicMin on (n1 - INT_MAX).
+__global__ __launch_bounds__(OCN_BLOCK) void cn5_column_stats(const int4* __restrict__ hist, i64 N,
+                                                              int32_t* __restrict__ scalars) {
+  int mn = 0x7fffffff, any1 = 0, anyu = 0;
+  for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (i64)gridDim.x * blockDim.x) {
+    int4 hc = hist[c];
+    if (hc.x >= 2 && hc.x < mn) mn = hc.x;
+    any1 |= hc.x > 0;
+    anyu |= hc.z > 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int t = __shfl_xor(mn, o, OCN_WAVE);
+    mn = t < mn ? t : mn;
+    any1 |= __shfl_xor(any1, o, OCN_WAVE);
+    anyu |= __shfl_xor(anyu, o, OCN_WAVE);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    // slot 0 holds (min - INT_MAX) <= 0 so that a zeroed scratch means "none yet"
+    if (mn != 0x7fffffff) atomicMin(scalars + 0, mn - 0x7fffffff);
+    if (any1) atomicOr(scalars + 1, 1);
+    if (anyu) atomicOr(scalars + 2, 1);
+  }
+}
+
+__global__ __launch_bounds__(OCN_BLOCK) void cn5_column_weights(int4* __restrict__ hist, i64 N,
+                                                                const float* __restrict__ innerprod,
+                                                                const int32_t* __restrict__ scalars) {
+  // model.py:2370-2376: scale = max |ncn1| over the union-aligned vector (1.0 if it is empty)
+  const int mn = scalars[0] + 0x7fffffff;
+  float scale;
+  if (!scalars[2]) scale = 1.0f;
+  else if (scalars[0] != 0) scale = 1.0f / (float)mn;   // largest 1/S1 among columns with S1 >= 2
+  else scale = 0.0f;                                     // only singleton columns: all ncn1 values are 0
+  const float ip = innerprod[0];
+  const float nip = scale > 0.0f ? ip / scale : ip;
+  float4* wout = reinterpret_cast<float4*>(hist);
+  for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (i64)gridDim.x * blockDim.x) {
+    const int4 hc = hist[c];
+    if (hc.z == 0) continue;                             // untouched column: never read by the gather
+    const int n1 = hc.x, n2 = hc.y, nb = n1 + n2 - hc.z;
+    const float inv1 = n1 >= 2 ? 1.0f / (float)n1 : 0.0f;              // :2263-2266 (Q2)
+    const float t = __fmul_rn(nip, inv1);                              // nip * ncn1 value
+    const float v_both = __fsub_rn(1.0f, t);                           // :2380-2384
+    const float v_only2 = __fsub_rn(1.0f, __fmul_rn(nip, 0.0f));
+    const float v_only1 = __fsub_rn(0.0f, t);
+    // :2405-2406 column sum of v.  The reference adds the entries one by one in fp32 (edge
+    // order); here the three distinct values are combined by their integer multiplicities in
+    // fp64 and rounded once.  Exact whenever nip == 0 (then S2 = n2).
+    const double s2d = (double)(n2 - nb) * (double)v_only2 + (double)nb * (double)v_both +
+                       (double)(n1 - nb) * (double)v_only1;
+    float S2 = (float)s2d;
+    if (S2 == 0.0f) S2 = 1.0f;                                         // :2409
+    const float inv2 = 1.0f / S2;                                      // :2410
+    wout[c] = make_float4(inv1, __fmul_rn(v_both, inv2), __fmul_rn(v_only2, inv2),
+                          __fmul_rn(v_only1, inv2));                   // :2413
+  }
+}
+
+__global__ __launch_bounds__(OCN_BLOCK) void cn7_column_weights(int4* __restrict__ hist, i64 N,
+                                                                float sum_fill) {
+  float4* wout = reinterpret_cast<float4*>(hist);
+  for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (i64)gridDim.x * blockDim.x) {
+    const int4 hc = hist[c];
+    if (hc.z == 0) continue;
+    const float inv1 = hc.x >= 2 ? 1.0f / (float)hc.x : sum_fill;     // model.py:3116-3120
+    // x T0 == 1 (model.py:2958, 3141-3165); cn2 raw (Q5, :3186-3209)
+    wout[c] = make_float4(__fmul_rn(inv1, 1.0f), 1.0f, 1.0f, 0.0f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: pooling — gather embedding rows over the flagged neighbours
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void axpy4(float4& acc, float w, const float4& x) {
+  acc.x = __fadd_rn(acc.x, __fmul_rn(w, x.x));
+  acc.y = __fadd_rn(acc.y, __fmul_rn(w, x.y));
+  acc.z = __fadd_rn(acc.z, __fmul_rn(w, x.z));
+  acc.w = __fadd_rn(acc.w, __fmul_rn(w, x.w));
+}
+
+// LPE lanes cooperate on one edge; each lane owns NV float4 of the H = LPE*NV*4 features.
+template <int LPE, int NV>
+__global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
+    const i64* __restrict__ off, const uint8_t* __restrict__ flags,
+    const float4* __restrict__ weights, const float* __restrict__ h, int H,
+    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
+  constexpr int GPW = OCN_WAVE / LPE;
+  constexpr int UNR = 4;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane % LPE;
+  const int gbase = lane - gl;
+  const i64 e = ((i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
+  if (e >= B) return;                       // whole group leaves together
+  const i64 i = src[e], j = dst[e];
+  const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+  const i64 base = off[e];
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  const i64 rowq = H >> 2;                  // float4 per row
+
+  float4 acc1[NV], acc2[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (i64 p0 = 0; p0 < da; p0 += LPE) {
+    const i64 p = p0 + gl;
+    int32_t k = 0;
+    unsigned f = 0;
+    if (p < da) { k = colA[a0 + p]; f = flags[base + p]; }
+    float wa = 0.f, wb = 0.f;
+    if (f) {
+      const float4 w = weights[k];
+      wa = (f & OCN_F_CN1) ? w.x : 0.f;
+      wb = f == 3u ? w.y : (f == 2u ? w.z : w.w);
+    }
+    const bool need = (wa != 0.f) | (wb != 0.f);
+    unsigned long long m = __ballot(need);
+    if (LPE < 64) m = (m >> gbase) & ((1ull << (LPE & 63)) - 1ull);
+    while (m) {
+      int bsel[UNR];
+#pragma unroll
+      for (int t = 0; t < UNR; ++t) {
+        bsel[t] = m ? (__ffsll((long long)m) - 1) : -1;
+        m &= m - 1;                          // no-op once m == 0
+      }
+      int32_t kk[UNR];
+      float wwa[UNR], wwb[UNR];
+      float4 x[UNR][NV];
+#pragma unroll
+      for (int t = 0; t < UNR; ++t) {
+        const int sl = gbase + (bsel[t] < 0 ? 0 : bsel[t]);
+        kk[t] = __shfl(k, sl, OCN_WAVE);
+        wwa[t] = __shfl(wa, sl, OCN_WAVE);
+        wwb[t] = __shfl(wb, sl, OCN_WAVE);
+        if (bsel[t] >= 0) {
+          const float4* row = h4 + (i64)kk[t] * rowq + gl;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) x[t][v] = row[v * LPE];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < UNR; ++t) {
+        if (bsel[t] >= 0) {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            axpy4(acc1[v], wwa[t], x[t][v]);
+            axpy4(acc2[v], wwb[t], x[t][v]);
+          }
+        }
+      }
+    }
+  }
+  const float4* hi = h4 + i * rowq + gl;
+  const float4* hj = h4 + j * rowq + gl;
+  float4* o1 = reinterpret_cast<float4*>(xcn1) + e * rowq + gl;
+  float4* o2 = reinterpret_cast<float4*>(xcn2) + e * rowq + gl;
+  float4* o3 = reinterpret_cast<float4*>(xij) + e * rowq + gl;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const float4 a = hi[v * LPE], b = hj[v * LPE];
+    o1[v * LPE] = acc1[v];
+    o2[v * LPE] = acc2[v];
+    o3[v * LPE] = make_float4(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y), __fmul_rn(a.z, b.z),
+                              __fmul_rn(a.w, b.w));
+  }
+}
+
+// any H: one wave per edge, one feature per lane per 64-wide chunk (re-walks the flags per chunk)
+__global__ __launch_bounds__(OCN_BLOCK) void cn_gather_generic(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
+    const i64* __restrict__ off, const uint8_t* __restrict__ flags,
+    const float4* __restrict__ weights, const float* __restrict__ h, int H,
+    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
+  const int lane = threadIdx.x & 63;
+  const i64 e = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6);
+  if (e >= B) return;
+  const i64 i = src[e], j = dst[e];
+  const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+  const i64 base = off[e];
+  for (int f0 = 0; f0 < H; f0 += OCN_WAVE) {
+    const int ft = f0 + lane;
+    const bool fin = ft < H;
+    float acc1 = 0.f, acc2 = 0.f;
+    for (i64 p0 = 0; p0 < da; p0 += OCN_WAVE) {
+      const i64 p = p0 + lane;
+      int32_t k = 0;
+      unsigned f = 0;
+      if (p < da) { k = colA[a0 + p]; f = flags[base + p]; }
+      float wa = 0.f, wb = 0.f;
+      if (f) {
+        const float4 w = weights[k];
+        wa = (f & OCN_F_CN1) ? w.x : 0.f;
+        wb = f == 3u ? w.y : (f == 2u ? w.z : w.w);
+      }
+      unsigned long long m = __ballot((wa != 0.f) | (wb != 0.f));
+      while (m) {
+        const int b = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int32_t kk = __shfl(k, b, OCN_WAVE);
+        const float a = __shfl(wa, b, OCN_WAVE), bb = __shfl(wb, b, OCN_WAVE);
+        if (fin) {
+          const float x = h[(i64)kk * H + ft];
+          acc1 = __fadd_rn(acc1, __fmul_rn(a, x));
+          acc2 = __fadd_rn(acc2, __fmul_rn(bb, x));
+        }
+      }
+    }
+    if (fin) {
+      xcn1[e * H + ft] = acc1;
+      xcn2[e * H + ft] = acc2;
+      xij[e * H + ft] = __fmul_rn(h[i * H + ft], h[j * H + ft]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// encoder SpMM
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OCN_BLOCK) void deg_rsqrt_kernel(const i64* __restrict__ rowptr, i64 n,
+                                                              float add, float* __restrict__ out) {
+  for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
+    const float d = add + (float)(rowptr[r + 1] - rowptr[r]);
+    out[r] = d > 0.f ? 1.0f / sqrtf(d) : 0.f;
+  }
+}
+
+enum { SPMM_SUM = 0, SPMM_MEAN = 1, SPMM_MAX = 2 };
+
+template <int MODE>
+__device__ __forceinline__ void red4(float4& acc, float w, bool weighted, const float4& x) {
+  if (MODE == SPMM_MAX) {
+    acc.x = fmaxf(acc.x, x.x); acc.y = fmaxf(acc.y, x.y);
+    acc.z = fmaxf(acc.z, x.z); acc.w = fmaxf(acc.w, x.w);
+  } else if (weighted) {
+    axpy4(acc, w, x);
+  } else {
+    acc.x = __fadd_rn(acc.x, x.x); acc.y = __fadd_rn(acc.y, x.y);
+    acc.z = __fadd_rn(acc.z, x.z); acc.w = __fadd_rn(acc.w, x.w);
+  }
+}
+
+template <int LPE, int NV, int MODE>
+__global__ __launch_bounds__(OCN_BLOCK) void spmm_csr_kernel(
+    const i64* __restrict__ rowptr, const int32_t* __restrict__ col, i64 n_rows,
+    const float* __restrict__ x, int F, const float* __restrict__ pre,
+    const float* __restrict__ post, int edge_scale, int self_mode, float* __restrict__ y) {
+  constexpr int GPW = OCN_WAVE / LPE;
+  constexpr int UNR = 4;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane % LPE;
+  const int gbase = lane - gl;
+  const i64 r = ((i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
+  if (r >= n_rows) return;
+  const i64 a0 = rowptr[r], da = rowptr[r + 1] - a0;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  const i64 rowq = F >> 2;
+  const bool weighted = pre != nullptr;
+  const float pr = weighted ? pre[r] : 1.0f;
+
+  float4 acc[NV];
+  const float init = MODE == SPMM_MAX ? -INFINITY : 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = make_float4(init, init, init, init);
+
+  // the row's own term: weight pre[r] (edge_scale 0) or fl(pre[r]*pre[r]) (edge_scale 1)
+  const float wself = weighted ? (edge_scale ? __fmul_rn(pr, pr) : pr) : 1.0f;
+  bool self_done = self_mode != 2;
+  i64 seen = 0;
+
+  for (i64 p0 = 0; p0 < da; p0 += LPE) {
+    const i64 p = p0 + gl;
+    int32_t k = 0;
+    float wk = 1.0f;
+    if (p < da) {
+      k = col[a0 + p];
+      if (weighted) wk = edge_scale ? __fmul_rn(pr, pre[k]) : pre[k];
+    }
+    const int cnt = (int)((da - p0) < LPE ? (da - p0) : LPE);
+    for (int b0 = 0; b0 < cnt; b0 += UNR) {
+      int32_t kk[UNR];
+      float ww[UNR];
+      float4 xv[UNR][NV];
+#pragma unroll
+      for (int t = 0; t < UNR; ++t) {
+        const int b = b0 + t;
+        const int sl = gbase + (b < cnt ? b : 0);
+        kk[t] = __shfl(k, sl, OCN_WAVE);
+        ww[t] = __shfl(wk, sl, OCN_WAVE);
+        if (b < cnt) {
+          const float4* row = x4 + (i64)kk[t] * rowq + gl;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) xv[t][v] = row[v * LPE];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < UNR; ++t) {
+        if (b0 + t < cnt) {
+          if (!self_done && (i64)kk[t] >= r) {
+            // sorted position of the diagonal (fill_diag): add it before the first column >= r
+            const float4* row = x4 + r * rowq + gl;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) red4<MODE>(acc[v], wself, weighted, row[v * LPE]);
+            self_done = true;
+            ++seen;
+            if ((i64)kk[t] == r) continue;   // an explicit self loop is replaced, not doubled
+          }
+#pragma unroll
+          for (int v = 0; v < NV; ++v) red4<MODE>(acc[v], ww[t], weighted, xv[t][v]);
+          ++seen;
+        }
+      }
+    }
+  }
+  if (self_mode == 1 || !self_done) {
+    const float4* row = x4 + r * rowq + gl;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) red4<MODE>(acc[v], wself, weighted, row[v * LPE]);
+    ++seen;
+  }
+  const float po = post ? post[r] : 1.0f;
+  float4* o = reinterpret_cast<float4*>(y) + r * rowq + gl;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    float4 a = acc[v];
+    if (MODE == SPMM_MEAN) {
+      const float d = (float)(seen > 0 ? seen : 1);
+      a.x /= d; a.y /= d; a.z /= d; a.w /= d;
+    }
+    if (MODE == SPMM_MAX && seen == 0) a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (post) { a.x = __fmul_rn(po, a.x); a.y = __fmul_rn(po, a.y); a.z = __fmul_rn(po, a.z); a.w = __fmul_rn(po, a.w); }
+    o[v * LPE] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// A*A pattern: one workgroup per output row, the row's column set as a bitmap in LDS
+// ---------------------------------------------------------------------------------------------
+#define SPGEMM_MAX_LDS (160 * 1024 - 2048)
+
+template <bool FILL>
+__global__ __launch_bounds__(OCN_BLOCK) void spgemm_pattern_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA, i64 n_rows,
+    const i64* __restrict__ rowptrB, const int32_t* __restrict__ colB, i64 n_colsB,
+    int32_t* __restrict__ row_count, const i64* __restrict__ rowptrC, int32_t* __restrict__ colC) {
+  extern __shared__ __attribute__((aligned(16))) unsigned bm[];
+  __shared__ i64 sh[2 * OCN_WPB];
+  const int words = (int)((n_colsB + 31) >> 5);
+  const int wpt = (words + OCN_BLOCK - 1) / OCN_BLOCK;       // contiguous words per thread
+  const int w0 = threadIdx.x * wpt;
+  const int w1 = (w0 + wpt) < words ? (w0 + wpt) : words;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int w = threadIdx.x; w < words; w += OCN_BLOCK) bm[w] = 0u;
+  __syncthreads();
+  for (i64 r = blockIdx.x; r < n_rows; r += gridDim.x) {
+    const i64 a0 = rowptrA[r], da = rowptrA[r + 1] - a0;
+    for (i64 q = wave; q < da; q += OCN_WPB) {
+      const i64 m = colA[a0 + q];
+      const i64 b0 = rowptrB[m], db = rowptrB[m + 1] - b0;
+      for (i64 t = lane; t < db; t += OCN_WAVE) {
+        const unsigned k = (unsigned)colB[b0 + t];
+        atomicOr(&bm[k >> 5], 1u << (k & 31u));
+      }
+    }
+    __syncthreads();
+    i64 c = 0;
+    for (int w = w0; w < w1; ++w) c += __popc(bm[w]);
+    i64 tot;
+    i64 ex = block_excl_scan(c, sh, &tot);
+    if (!FILL) {
+      if (threadIdx.x == 0) row_count[r] = (int32_t)tot;
+      for (int w = w0; w < w1; ++w) bm[w] = 0u;
+    } else {
+      int32_t* out = colC + rowptrC[r] + ex;
+      for (int w = w0; w < w1; ++w) {
+        unsigned bits = bm[w];
+        bm[w] = 0u;
+        while (bits) {
+          const int b = __ffs((int)bits) - 1;
+          bits &= bits - 1;
+          *out++ = (w << 5) + b;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int ocn_abi_version(void) { return OCN_ABI_VERSION; }
+
+int64_t ocn_scan_workspace_bytes(int64_t n) {
+  i64 nt = (n + SCAN_TILE - 1) / SCAN_TILE;
+  return (nt + 2) * (int64_t)sizeof(i64);
+}
+
+int ocn_edge_offsets(const int64_t* rowptrA, const int64_t* src, int64_t B, int64_t* off,
+                     void* workspace, void* stream) {
+  if (!rowptrA || (!src && B > 0)) return OCN_EINVAL;
+  DegOfSrc op{(const i64*)rowptrA, (const i64*)src};
+  return run_scan(op, B, (i64*)off, workspace, (hipStream_t)stream);
+}
+
+int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, void* stream) {
+  if (!in && n > 0) return OCN_EINVAL;
+  I32In op{in};
+  return run_scan(op, n, (i64*)out, workspace, (hipStream_t)stream);
+}
+
+int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* rowptrT1,
+                 const int32_t* colT1, const int64_t* rowptrT2, const int32_t* colT2,
+                 const int64_t* src, const int64_t* dst, int64_t B, const int64_t* off,
+                 uint8_t* flags, int64_t flags_cap, int32_t* hist, int32_t* cnt1, int32_t* cnt2,
+                 int32_t* status, void* stream) {
+  if (B < 0 || flags_cap < 0) return OCN_EINVAL;
+  if (B == 0) return 0;
+  if (!rowptrA || !rowptrT1 || !src || !dst || !off || !hist || !cnt1 || !status) return OCN_EINVAL;
+  if ((rowptrT2 == nullptr) != (colT2 == nullptr)) return OCN_EINVAL;
+  const int grid = grid_for((B + OCN_WPB - 1) / OCN_WPB);
+  hipStream_t st = (hipStream_t)stream;
+  if (rowptrT2)
+    hipLaunchKernelGGL(cn_flags_kernel<true>, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
+                       colA, (const i64*)rowptrT1, colT1, (const i64*)rowptrT2, colT2, (const i64*)src,
+                       (const i64*)dst, (i64)B, (const i64*)off, flags, (i64)flags_cap, hist, cnt1, cnt2,
+                       status);
+  else
+    hipLaunchKernelGGL(cn_flags_kernel<false>, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
+                       colA, (const i64*)rowptrT1, colT1, (const i64*)nullptr, (const int32_t*)nullptr,
+                       (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, (i64)flags_cap,
+                       hist, cnt1, cnt2, status);
+  return launch_status();
+}
+
+int ocn_cn_weights_cn5(int32_t* hist, int64_t N, const float* innerprod, int32_t* scalars,
+                       void* stream) {
+  if (N < 0 || (N > 0 && (!hist || !innerprod || !scalars))) return OCN_EINVAL;
+  if (N == 0) return 0;
+  const int grid = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cn5_column_stats, dim3(grid), dim3(OCN_BLOCK), 0, st, (const int4*)hist, (i64)N,
+                     scalars);
+  hipLaunchKernelGGL(cn5_column_weights, dim3(grid), dim3(OCN_BLOCK), 0, st, (int4*)hist, (i64)N,
+                     innerprod, (const int32_t*)scalars);
+  return launch_status();
+}
+
+int ocn_cn_weights_cn7(int32_t* hist, int64_t N, float sum_fill, void* stream) {
+  if (N < 0 || (N > 0 && !hist)) return OCN_EINVAL;
+  if (N == 0) return 0;
+  const int grid = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
+  hipLaunchKernelGGL(cn7_column_weights, dim3(grid), dim3(OCN_BLOCK), 0, (hipStream_t)stream,
+                     (int4*)hist, (i64)N, sum_fill);
+  return launch_status();
+}
+
+#define GATHER_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, \
+                    flags, (const float4*)weights, h, (int)H, xcn1, xcn2, xij
+#define LAUNCH_GATHER(LPE, NV)                                                                      \
+  do {                                                                                              \
+    const i64 epb = (i64)OCN_WPB * (OCN_WAVE / (LPE));                                              \
+    hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)),          \
+                       dim3(OCN_BLOCK), 0, st, GATHER_ARGS);                                        \
+  } while (0)
+
+int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
+                  const int64_t* dst, int64_t B, const int64_t* off, const uint8_t* flags,
+                  const float* weights, const float* h, int32_t H, float* xcn1, float* xcn2,
+                  float* xij, void* stream) {
+  if (B < 0 || H <= 0) return OCN_EINVAL;
+  if (B == 0) return 0;
+  if (!rowptrA || !src || !dst || !off || !weights || !h || !xcn1 || !xcn2 || !xij) return OCN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  switch (H) {
+    case 16:  LAUNCH_GATHER(4, 1); break;
+    case 32:  LAUNCH_GATHER(8, 1); break;
+    case 64:  LAUNCH_GATHER(16, 1); break;
+    case 128: LAUNCH_GATHER(32, 1); break;
+    case 256: LAUNCH_GATHER(64, 1); break;
+    case 512: LAUNCH_GATHER(64, 2); break;
+    default:
+      hipLaunchKernelGGL(cn_gather_generic, dim3((unsigned)((B + OCN_WPB - 1) / OCN_WPB)),
+                         dim3(OCN_BLOCK), 0, st, GATHER_ARGS);
+  }
+  return launch_status();
+}
+
+#define SPMM_ARGS (const i64*)rowptr, col, (i64)n_rows, x, (int)F, pre, post, (int)edge_scale, \
+                  (int)self_mode, y
+#define LAUNCH_SPMM(LPE, NV, MODE)                                                                  \
+  do {                                                                                              \
+    const i64 rpb = (i64)OCN_WPB * (OCN_WAVE / (LPE));                                              \
+    hipLaunchKernelGGL((spmm_csr_kernel<LPE, NV, MODE>), dim3((unsigned)((n_rows + rpb - 1) / rpb)),\
+                       dim3(OCN_BLOCK), 0, st, SPMM_ARGS);                                          \
+  } while (0)
+#define DISPATCH_SPMM(MODE)                                                                         \
+  do {                                                                                              \
+    if (F == 16) LAUNCH_SPMM(4, 1, MODE);                                                           \
+    else if (F == 32) LAUNCH_SPMM(8, 1, MODE);                                                      \
+    else if (F == 64) LAUNCH_SPMM(16, 1, MODE);                                                     \
+    else if (F == 128) LAUNCH_SPMM(32, 1, MODE);                                                    \
+    else if (F == 256) LAUNCH_SPMM(64, 1, MODE);                                                    \
+    else if (F == 512) LAUNCH_SPMM(64, 2, MODE);                                                    \
+    else return OCN_EINVAL; /* feature widths of the reference configs only (16..512, pow2) */      \
+  } while (0)
+
+int ocn_spmm_csr(const int64_t* rowptr, const int32_t* col, int64_t n_rows, const float* x,
+                 int32_t F, const float* pre, const float* post, int32_t mode, int32_t edge_scale,
+                 int32_t self_mode, float* y, void* stream) {
+  if (n_rows < 0 || F <= 0 || mode < 0 || mode > 2 || self_mode < 0 || self_mode > 2) return OCN_EINVAL;
+  if (n_rows == 0) return 0;
+  if (!rowptr || !x || !y) return OCN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == SPMM_SUM) DISPATCH_SPMM(SPMM_SUM);
+  else if (mode == SPMM_MEAN) DISPATCH_SPMM(SPMM_MEAN);
+  else DISPATCH_SPMM(SPMM_MAX);
+  return launch_status();
+}
+
+int ocn_deg_rsqrt(const int64_t* rowptr, int64_t n_rows, float add, float* out, void* stream) {
+  if (n_rows < 0 || (n_rows > 0 && (!rowptr || !out))) return OCN_EINVAL;
+  if (n_rows == 0) return 0;
+  const int grid = grid_for((n_rows + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
+  hipLaunchKernelGGL(deg_rsqrt_kernel, dim3(grid), dim3(OCN_BLOCK), 0, (hipStream_t)stream,
+                     (const i64*)rowptr, (i64)n_rows, add, out);
+  return launch_status();
+}
+
+int64_t ocn_spgemm_max_cols(void) { return (int64_t)SPGEMM_MAX_LDS * 8; }
+
+static int spgemm_launch(bool fill, const int64_t* rowptrA, const int32_t* colA, int64_t n_rows,
+                         const int64_t* rowptrB, const int32_t* colB, int64_t n_colsB,
+                         int32_t* row_count, const int64_t* rowptrC, int32_t* colC, void* stream) {
+  if (n_rows < 0 || n_colsB <= 0 || n_colsB > ocn_spgemm_max_cols()) return OCN_EINVAL;
+  if (n_rows == 0) return 0;
+  if (!rowptrA || !rowptrB) return OCN_EINVAL;
+  const size_t lds = (size_t)(((n_colsB + 31) >> 5) * 4);
+  const int per_cu = (int)((160 * 1024) / (lds + 256));
+  int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
+  if (grid > n_rows) grid = (int)n_rows;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t err;
+  if (fill) {
+    err = hipFuncSetAttribute((const void*)spgemm_pattern_kernel<true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    hipLaunchKernelGGL(spgemm_pattern_kernel<true>, dim3(grid), dim3(OCN_BLOCK), lds, st,
+                       (const i64*)rowptrA, colA, (i64)n_rows, (const i64*)rowptrB, colB, (i64)n_colsB,
+                       row_count, (const i64*)rowptrC, colC);
+  } else {
+    err = hipFuncSetAttribute((const void*)spgemm_pattern_kernel<false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (err != hipSuccess) return (int)err;
+    hipLaunchKernelGGL(spgemm_pattern_kernel<false>, dim3(grid), dim3(OCN_BLOCK), lds, st,
+                       (const i64*)rowptrA, colA, (i64)n_rows, (const i64*)rowptrB, colB, (i64)n_colsB,
+                       row_count, (const i64*)rowptrC, colC);
+  }
+  return launch_status();
+}
+
+int ocn_spgemm_pattern_count(const int64_t* rowptrA, const int32_t* colA, int64_t n_rows,
+                             const int64_t* rowptrB, const int32_t* colB, int64_t n_colsB,
+                             int32_t* row_count, void* stream) {
+  if (!row_count && n_rows > 0) return OCN_EINVAL;
+  return spgemm_launch(false, rowptrA, colA, n_rows, rowptrB, colB, n_colsB, row_count, nullptr,
+                       nullptr, stream);
+}
+
+int ocn_spgemm_pattern_fill(const int64_t* rowptrA, const int32_t* colA, int64_t n_rows,
+                            const int64_t* rowptrB, const int32_t* colB, int64_t n_colsB,
+                            const int64_t* rowptrC, int32_t* colC, void* stream) {
+  if ((!rowptrC || !colC) && n_rows > 0) return OCN_EINVAL;
+  return spgemm_launch(true, rowptrA, colA, n_rows, rowptrB, colB, n_colsB, nullptr, rowptrC, colC,
+                       stream);
+}
+
+}  // extern "C"

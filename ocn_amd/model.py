@@ -1,0 +1,361 @@
+"""Drop-in for the hot-path classes of the reference's ``model.py``.
+
+Exports ``predictor_dict`` (``cn5`` = CNLinkPredictorOringin, model.py:2171-2443; ``cn7`` =
+CNLinkPredictorbaselearn, model.py:3021-3229), ``convdict`` / ``convdict2`` / ``convdict3``,
+``GCN`` / ``GCN2`` / ``GCN3`` (model.py:232-511), ``PureConv*``, ``DropAdj``, ``DropEdge`` with the
+reference's constructor signatures and ``state_dict`` key layout, so checkpoints and the unchanged
+drivers work.  The sparse arithmetic runs in libocn_hip.so (no torch_sparse / pygho / PyG); the
+dense ``Linear`` / ``LayerNorm`` heads stay torch modules (rocBLAS fp32).
+"""
+from __future__ import annotations
+
+from typing import Final, Iterable
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import ops
+from .sparse import SparseTensor
+from .utils import fuse
+
+
+# ------------------------------------------------------------------------------------------
+# edge dropout (model.py:198-229) — identity in eval; train-time regulariser
+# ------------------------------------------------------------------------------------------
+class DropEdge(nn.Module):
+    def __init__(self, dp: float = 0.0) -> None:
+        super().__init__()
+        self.dp = dp
+
+    def forward(self, edge_index: Tensor):
+        if self.dp == 0:
+            return edge_index
+        mask = torch.rand_like(edge_index[0], dtype=torch.float) > self.dp
+        return edge_index[:, mask]
+
+
+class DropAdj(nn.Module):
+    doscale: Final[bool]
+
+    def __init__(self, dp: float = 0.0, doscale=True) -> None:
+        super().__init__()
+        self.dp = dp
+        self.register_buffer("ratio", torch.tensor(1 / (1 - dp)))
+        self.doscale = doscale
+
+    def forward(self, adj: SparseTensor) -> SparseTensor:
+        if self.dp < 1e-6 or not self.training:
+            return adj
+        row, col, val = adj.coo()
+        mask = torch.rand_like(col, dtype=torch.float) > self.dp
+        if self.doscale:
+            val = (val[mask] * self.ratio) if val is not None else torch.full(
+                (int(mask.sum()),), 1 / (1 - self.dp), device=col.device)
+        else:
+            val = None if val is None else val[mask]
+        return SparseTensor(row=row[mask], col=col[mask], value=val, sparse_sizes=adj.sparse_sizes(),
+                            is_sorted=True, trust_data=True)
+
+
+# ------------------------------------------------------------------------------------------
+# message passing layers
+# ------------------------------------------------------------------------------------------
+def _no_values(adj: SparseTensor, who: str) -> None:
+    if adj.has_value():
+        raise NotImplementedError(f"{who}: valued adjacencies (train-time DropAdj rescale) are not on "
+                                  "the forward-only path")
+
+
+class PureConv(nn.Module):
+    """model.py:32-55 — parameter-free aggregation; ``gcn`` = n ⊙ (A(n ⊙ x) + n ⊙ x), n = (1+deg)^-½."""
+    aggr: Final[str]
+
+    def __init__(self, indim, outdim, aggr="gcn") -> None:
+        super().__init__()
+        self.aggr = aggr
+        if indim == outdim:
+            self.lin = nn.Identity()
+        else:
+            raise NotImplementedError
+
+    def forward(self, x, adj_t: SparseTensor):
+        x = self.lin(x).contiguous()
+        _no_values(adj_t, "PureConv")
+        if self.aggr in ("mean", "max", "sum"):
+            return ops.spmm_csr(adj_t._rowptr, adj_t._col, x, mode=self.aggr)
+        if self.aggr == "gcn":
+            norm = ops.deg_rsqrt(adj_t._rowptr, 1.0)
+            return ops.spmm_csr(adj_t._rowptr, adj_t._col, x, pre=norm, post=norm, mode="sum",
+                                edge_scale=False, self_mode=1)
+        raise ValueError(self.aggr)
+
+
+class GCNConv(nn.Module):
+    """The slice of torch_geometric.nn.GCNConv that ``convdict`` uses (model.py:58-72): a bias-free
+    ``lin``, propagation over ``adj_t`` with ``aggr``, then ``+ bias``.  ``normalize`` applies
+    D̃^-½(A+I)D̃^-½.  Parameter names (``lin.weight``, ``bias``) follow PyG 2.6.1."""
+
+    def __init__(self, in_channels, out_channels, aggr="add", normalize=True, add_self_loops=True,
+                 cached=False, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.aggr = "sum" if aggr == "add" else aggr
+        self.normalize, self.add_self_loops = normalize, add_self_loops
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        nn.init.xavier_uniform_(self.lin.weight)            # PyG: glorot weight, zero bias
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+
+    def forward(self, x, adj_t: SparseTensor):
+        _no_values(adj_t, "GCNConv")
+        x = self.lin(x).contiguous()
+        if self.normalize:
+            dinv = ops.deg_rsqrt(adj_t._rowptr, 1.0)        # degree of A + I (A has no self loops)
+            out = ops.spmm_csr(adj_t._rowptr, adj_t._col, x, pre=dinv, mode="sum", edge_scale=True,
+                               self_mode=2 if self.add_self_loops else 0)
+        else:
+            out = ops.spmm_csr(adj_t._rowptr, adj_t._col, x, mode=self.aggr)
+        return out if self.bias is None else out + self.bias
+
+
+convdict = {
+    "gcn": GCNConv,
+    "gcn_cached": lambda indim, outdim: GCNConv(indim, outdim, cached=True),
+    "sage": lambda indim, outdim: GCNConv(indim, outdim, aggr="mean", normalize=False, add_self_loops=False),
+    "gin": lambda indim, outdim: GCNConv(indim, outdim, aggr="sum", normalize=False, add_self_loops=False),
+    "max": lambda indim, outdim: GCNConv(indim, outdim, aggr="max", normalize=False, add_self_loops=False),
+    "puremax": lambda indim, outdim: PureConv(indim, outdim, aggr="max"),
+    "puresum": lambda indim, outdim: PureConv(indim, outdim, aggr="sum"),
+    "puremean": lambda indim, outdim: PureConv(indim, outdim, aggr="mean"),
+    "puregcn": lambda indim, outdim: PureConv(indim, outdim, aggr="gcn"),
+    "none": None,
+}
+
+
+class PureConv2(nn.Module):
+    """model.py:85-113 (and PureConv3, :115-142): aggregate first — ``gcn`` = (A ⊙ n nᵀ) x with no
+    self term — then optional ``Linear(no bias) + ReLU``."""
+    aggr: Final[str]
+
+    def __init__(self, indim, outdim, aggr="gcn", use_lin=False) -> None:
+        super().__init__()
+        self.aggr = aggr
+        if not use_lin:
+            if indim == outdim:
+                self.lin = nn.Identity()
+            else:
+                raise NotImplementedError
+        else:
+            self.lin = nn.Sequential(nn.Linear(indim, outdim, bias=False), nn.ReLU(inplace=True))
+
+    def forward(self, x, adj_t: SparseTensor):
+        _no_values(adj_t, "PureConv2")
+        x = x.contiguous()
+        if self.aggr in ("mean", "max", "sum"):
+            x = ops.spmm_csr(adj_t._rowptr, adj_t._col, x, mode=self.aggr)
+        elif self.aggr == "gcn":
+            norm = ops.deg_rsqrt(adj_t._rowptr, 1.0)
+            x = ops.spmm_csr(adj_t._rowptr, adj_t._col, x, pre=norm, mode="sum", edge_scale=True)
+        return self.lin(x)
+
+
+class PureConv3(PureConv2):
+    pass
+
+
+def _convdict23(cls):
+    return {
+        "gcn": lambda indim, outdim: cls(indim, outdim, aggr="gcn", use_lin=True),
+        "gcn_cached": lambda indim, outdim: cls(indim, outdim, aggr="gcn", use_lin=True),
+        "sage": lambda indim, outdim: cls(indim, outdim, aggr="mean", use_lin=True),
+        "gin": lambda indim, outdim: cls(indim, outdim, aggr="sum", use_lin=True),
+        "max": lambda indim, outdim: cls(indim, outdim, aggr="max", use_lin=True),
+        "puremax": lambda indim, outdim: cls(indim, outdim, aggr="max"),
+        "puresum": lambda indim, outdim: cls(indim, outdim, aggr="sum"),
+        "puremean": lambda indim, outdim: cls(indim, outdim, aggr="mean"),
+        "puregcn": lambda indim, outdim: cls(indim, outdim, aggr="gcn"),
+        "none": None,
+    }
+
+
+convdict2 = _convdict23(PureConv2)
+convdict3 = _convdict23(PureConv3)
+
+
+# ------------------------------------------------------------------------------------------
+# encoders
+# ------------------------------------------------------------------------------------------
+class _Encoder(nn.Module):
+    """Shared body of GCN / GCN2 / GCN3 (model.py:232-511): input embedding, L conv layers with
+    their LayerNorm/Dropout/ReLU tails, residual, JumpingKnowledge with raw weights."""
+    _convs = convdict
+    _use_adjdrop = True
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout, ln=False,
+                 res=False, max_x=-1, conv_fn="gcn", jk=False, edrop=0.0, xdropout=0.0,
+                 taildropout=0.0, noinputlin=False):
+        super().__init__()
+        self.adjdrop = DropAdj(edrop)
+        if max_x >= 0:
+            emb = nn.Embedding(max_x + 1, hidden_channels)
+            nn.init.orthogonal_(emb.weight)
+            self.xemb = nn.Sequential(emb, nn.Dropout(dropout))
+            in_channels = hidden_channels
+        else:
+            self.xemb = nn.Sequential(nn.Dropout(xdropout))
+            if not noinputlin and ("pure" in conv_fn or num_layers == 0):
+                self.xemb.append(nn.Linear(in_channels, hidden_channels))
+                self.xemb.append(nn.Dropout(dropout, inplace=True) if dropout > 1e-6 else nn.Identity())
+        self.res = res
+        self.jk = jk
+        if jk:
+            self.register_parameter("jkparams", nn.Parameter(torch.randn((num_layers,))))
+        if num_layers == 0 or conv_fn == "none":
+            self.jk = False
+            return
+        make = self._convs[conv_fn]
+        norm = (lambda dim: nn.LayerNorm(dim)) if ln else (lambda dim: nn.Identity())
+        if num_layers == 1:
+            hidden_channels = out_channels
+        self.convs = nn.ModuleList()
+        self.lins = nn.ModuleList()
+        if "pure" in conv_fn:
+            self.convs.append(make(hidden_channels, hidden_channels))
+            for _ in range(num_layers - 1):
+                self.lins.append(nn.Identity())
+                self.convs.append(make(hidden_channels, hidden_channels))
+            self.lins.append(nn.Dropout(taildropout, True))
+        else:
+            self.convs.append(make(in_channels, hidden_channels))
+            self.lins.append(nn.Sequential(norm(hidden_channels), nn.Dropout(dropout, True), nn.ReLU(True)))
+            for i in range(num_layers - 1):
+                last = i == num_layers - 2
+                self.convs.append(make(hidden_channels, hidden_channels if last else out_channels))
+                if not last:
+                    self.lins.append(nn.Sequential(norm(out_channels), nn.Dropout(dropout, True), nn.ReLU(True)))
+                else:
+                    self.lins.append(nn.Identity())
+
+    def forward(self, x, adj_t):
+        x = self.xemb(x)
+        jkx = []
+        for i, conv in enumerate(self.convs):
+            a = self.adjdrop(adj_t) if self._use_adjdrop else adj_t
+            x1 = self.lins[i](conv(x, a))
+            x = x1 + x if (self.res and x1.shape[-1] == x.shape[-1]) else x1
+            if self.jk:
+                jkx.append(x)
+        if self.jk:
+            x = torch.sum(torch.stack(jkx, dim=0) * self.jkparams.reshape(-1, 1, 1), dim=0)
+        return x
+
+
+class GCN(_Encoder):
+    """model.py:232-323."""
+
+
+class GCN2(_Encoder):
+    """model.py:326-417 — convdict2, no adjacency dropout inside the layer loop."""
+    _convs = convdict2
+    _use_adjdrop = False
+
+
+class GCN3(_Encoder):
+    """model.py:420-511."""
+    _convs = convdict3
+    _use_adjdrop = False
+
+
+# ------------------------------------------------------------------------------------------
+# predictors
+# ------------------------------------------------------------------------------------------
+class _CNPredictorBase(nn.Module):
+    """Parameters and MLP heads shared by cn5 and cn7 (model.py:2173-2239 ≡ 3023-3089).  The
+    ``nn.Sequential`` layouts are part of the checkpoint contract (state_dict keys)."""
+    cndeg: Final[int]
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout, edrop=0.0,
+                 ln=False, cndeg=-1, use_xlin=False, tailact=False, twolayerlin=False, beta=1.0):
+        super().__init__()
+        self.register_parameter("beta", nn.Parameter(beta * torch.ones((1))))
+        self.dropadj = DropAdj(edrop)
+        H, p = hidden_channels, dropout
+        norm = (lambda: nn.LayerNorm(H)) if ln else (lambda: nn.Identity())
+        drop = lambda: nn.Dropout(p, inplace=True)
+        relu = lambda: nn.ReLU(inplace=True)
+
+        def pooled_head(tail_identity=False):
+            return nn.Sequential(nn.Linear(in_channels, H), drop(), relu(), nn.Linear(H, H), norm(),
+                                 drop(), relu(), nn.Identity() if tail_identity else nn.Linear(H, H))
+
+        self.xlin = nn.Sequential(nn.Linear(H, H), drop(), relu(), nn.Linear(H, H), norm(), drop(),
+                                  relu()) if use_xlin else (lambda x: 0)
+        self.xcnlin = pooled_head(tail_identity=tailact)     # allocated, unused by cn5/cn7 forward
+        self.xcn1lin = pooled_head()
+        self.xcn2lin = pooled_head()
+        self.xcn4lin = pooled_head()                         # allocated, unused
+        self.xijlin = nn.Sequential(nn.Linear(in_channels, H), norm(), drop(), relu(),
+                                    nn.Identity() if tailact else nn.Linear(H, H))
+        two = twolayerlin
+        self.lin = nn.Sequential(nn.Linear(H, H), norm(), drop(), relu(),
+                                 nn.Linear(H, H) if two else nn.Identity(),
+                                 norm() if two else nn.Identity(),
+                                 drop() if two else nn.Identity(),
+                                 relu() if two else nn.Identity(),
+                                 nn.Linear(H, out_channels))
+        self.cndeg = cndeg
+        self.register_parameter("alpha", nn.Parameter(torch.ones((3))))
+        self.register_buffer("innerprod", torch.tensor([0.0]))
+        self.n = 0
+
+    def _no_backward(self, x: Tensor) -> None:
+        if torch.is_grad_enabled() and (x.requires_grad or self.training):
+            raise NotImplementedError(
+                "ocn_amd predictors are forward-only this round: call under torch.no_grad() / .eval() "
+                "(autograd for the fused pooling is the next scope row, SURVEY.md §8f-1)")
+
+    def _heads(self, x, xcn1, xcn2, xij):
+        xij = self.xijlin(xij)
+        xcn1 = self.xcn1lin(xcn1)
+        xcn2 = self.xcn2lin(xcn2)
+        alpha = torch.sigmoid(self.alpha).cumprod(-1)
+        return self.lin(alpha[0] * xcn1 + alpha[1] * xcn2 + self.beta * xij)
+
+
+class CNLinkPredictorOringin(_CNPredictorBase):
+    """cn5 (model.py:2171-2443): column-normalised cn1, cn2 orthogonalised against it with the
+    running inner product, column-normalised again; pooled embeddings -> MLP heads -> logit."""
+
+    def multidomainforward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False,
+                           cndropprobs: Iterable[float] = []):
+        self._no_backward(x)
+        st = fuse(cn1, cn2, tar_ei)
+        w = st.weights_cn5(self.innerprod)
+        xcn1, xcn2, xij = st.gather(w, x.contiguous())
+        return self._heads(x, xcn1, xcn2, xij)
+
+    def forward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False):
+        return self.multidomainforward(x, adj, cn1, cn2, tar_ei, filled1, [])
+
+
+class CNLinkPredictorbaselearn(_CNPredictorBase):
+    """cn7 (model.py:3021-3229): cn1 column-normalised with ``args.sum`` for columns hit fewer than
+    twice, Chebyshev diagonal hard-wired to T0 = identity, raw cn2; same heads."""
+
+    def multidomainforward(self, x, adj, cn1, cn2, tar_ei, args, filled1: bool = False,
+                           cndropprobs: Iterable[float] = []):
+        self._no_backward(x)
+        st = fuse(cn1, cn2, tar_ei)
+        w = st.weights_cn7(float(args.sum))
+        xcn1, xcn2, xij = st.gather(w, x.contiguous())
+        return self._heads(x, xcn1, xcn2, xij)
+
+    def forward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False):
+        # the drivers pass the argparse Namespace in this slot (NeighborOverlap_large.py:122)
+        return self.multidomainforward(x, adj, cn1, cn2, tar_ei, filled1, [])
+
+
+predictor_dict = {
+    "cn5": CNLinkPredictorOringin,
+    "cn7": CNLinkPredictorbaselearn,
+}

@@ -1,0 +1,174 @@
+"""Host-side wrappers of the C ABI: argument validation + raw-pointer calls.
+
+torch is used for device memory and the current stream only.  Every function here requires
+CUDA(HIP) tensors and raises if the library is missing — there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+FLAGS_NOSYNC_LIMIT = 1 << 30     # bytes of flag buffer we are willing to over-allocate to avoid a host sync
+validate_indices = True          # bounds-check candidate edges on the host side (one sync per batch)
+
+
+def _req(t: Tensor, dtype, name: str, ndim: Optional[int] = None) -> Tensor:
+    if not isinstance(t, Tensor) or not t.is_cuda:
+        raise _lib.OcnHipError(f"{name}: expected a CUDA/HIP tensor — ocn_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if ndim is not None and t.dim() != ndim:
+        raise ValueError(f"{name}: expected {ndim}-d, got shape {tuple(t.shape)}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return t
+
+
+def _ws(n: int, device) -> Tensor:
+    return torch.empty(int(_lib.lib().ocn_scan_workspace_bytes(n)) // 8 + 1, dtype=torch.int64, device=device)
+
+
+def edge_offsets(rowptr: Tensor, src: Tensor) -> Tensor:
+    _req(rowptr, torch.int64, "rowptr", 1)
+    _req(src, torch.int64, "src", 1)
+    B = src.numel()
+    off = torch.empty(B + 1, dtype=torch.int64, device=src.device)
+    ws = _ws(B, src.device)
+    check(_lib.lib().ocn_edge_offsets(ptr(rowptr), ptr(src), B, ptr(off), ptr(ws), stream_ptr()),
+          "ocn_edge_offsets")
+    return off
+
+
+def scan_i32(cnt: Tensor) -> Tensor:
+    _req(cnt, torch.int32, "cnt", 1)
+    n = cnt.numel()
+    out = torch.empty(n + 1, dtype=torch.int64, device=cnt.device)
+    ws = _ws(n, cnt.device)
+    check(_lib.lib().ocn_scan_i32(ptr(cnt), n, ptr(out), ptr(ws), stream_ptr()), "ocn_scan_i32")
+    return out
+
+
+def check_edges(src: Tensor, dst: Tensor, n_src: int, n_dst: int) -> None:
+    """Reference behaviour for an out-of-range node id is an IndexError from index_select; a raw
+    kernel would fault instead, so the ids are checked here (costs one host sync)."""
+    if not validate_indices or src.numel() == 0:
+        return
+    lo = torch.minimum(src.min(), dst.min())
+    bad = (lo < 0) | (src.max() >= n_src) | (dst.max() >= n_dst)
+    if bool(bad):
+        raise IndexError("candidate edge endpoint out of range for the adjacency")
+
+
+def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Tuple[Tensor, Tensor], t2: Optional[Tuple[Tensor, Tensor]],
+             src: Tensor, dst: Tensor, n_cols: int, max_deg_a: int):
+    """Returns (off, flags, hist[N,4] int32, cnt1, cnt2|None, status)."""
+    dev = src.device
+    B = src.numel()
+    _req(rowptrA, torch.int64, "rowptrA", 1); _req(colA, torch.int32, "colA", 1)
+    _req(t1[0], torch.int64, "rowptrT1", 1); _req(t1[1], torch.int32, "colT1", 1)
+    if t2 is not None:
+        _req(t2[0], torch.int64, "rowptrT2", 1); _req(t2[1], torch.int32, "colT2", 1)
+    _req(src, torch.int64, "src", 1); _req(dst, torch.int64, "dst", 1)
+    if dst.numel() != B:
+        raise ValueError("src/dst length mismatch")
+    off = edge_offsets(rowptrA, src)
+    bound = B * max(int(max_deg_a), 0)
+    cap = bound if bound <= FLAGS_NOSYNC_LIMIT else int(off[-1].item())
+    flags = torch.empty(max(cap, 1), dtype=torch.uint8, device=dev)
+    hist = torch.zeros(n_cols, 4, dtype=torch.int32, device=dev)
+    cnt1 = torch.empty(B, dtype=torch.int32, device=dev)
+    cnt2 = torch.empty(B, dtype=torch.int32, device=dev) if t2 is not None else None
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(_lib.lib().ocn_cn_flags(ptr(rowptrA), ptr(colA), ptr(t1[0]), ptr(t1[1]),
+                                  ptr(t2[0] if t2 else None), ptr(t2[1] if t2 else None),
+                                  ptr(src), ptr(dst), B, ptr(off), ptr(flags), cap, ptr(hist),
+                                  ptr(cnt1), ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_flags")
+    return off, flags, hist, cnt1, cnt2, status
+
+
+def cn_weights_cn5(hist: Tensor, innerprod: Tensor) -> Tensor:
+    """In place: int32 [N,4] histogram -> float32 [N,4] weights (same storage)."""
+    _req(hist, torch.int32, "hist", 2)
+    ip = _req(innerprod.detach().reshape(1).to(torch.float32), torch.float32, "innerprod", 1)
+    scal = torch.zeros(4, dtype=torch.int32, device=hist.device)
+    check(_lib.lib().ocn_cn_weights_cn5(ptr(hist), hist.shape[0], ptr(ip), ptr(scal), stream_ptr()),
+          "ocn_cn_weights_cn5")
+    return hist.view(torch.float32)
+
+
+def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
+    _req(hist, torch.int32, "hist", 2)
+    check(_lib.lib().ocn_cn_weights_cn7(ptr(hist), hist.shape[0], float(sum_fill), stream_ptr()),
+          "ocn_cn_weights_cn7")
+    return hist.view(torch.float32)
+
+
+def cn_gather(rowptrA, colA, src, dst, off, flags, weights: Tensor, h: Tensor):
+    _req(weights, torch.float32, "weights", 2)
+    _req(h, torch.float32, "h", 2)
+    if weights.shape[0] != h.shape[0] or weights.shape[1] != 4:
+        raise ValueError("weights must be [N,4] with N = h.shape[0]")
+    B, H = src.numel(), h.shape[1]
+    out = torch.empty(3, B, H, dtype=torch.float32, device=h.device)
+    check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), B, ptr(off), ptr(flags),
+                                   ptr(weights), ptr(h), H, ptr(out[0]), ptr(out[1]), ptr(out[2]),
+                                   stream_ptr()), "ocn_cn_gather")
+    return out[0], out[1], out[2]
+
+
+SPMM_MODES = {"sum": 0, "add": 0, "mean": 1, "max": 2}
+
+
+def spmm_csr(rowptr: Tensor, col: Tensor, x: Tensor, pre: Optional[Tensor] = None,
+             post: Optional[Tensor] = None, mode: str = "sum", edge_scale: bool = False,
+             self_mode: int = 0) -> Tensor:
+    _req(rowptr, torch.int64, "rowptr", 1); _req(col, torch.int32, "col", 1)
+    _req(x, torch.float32, "x", 2)
+    n = rowptr.numel() - 1
+    if pre is not None and (_req(pre, torch.float32, "pre", 1).numel() != x.shape[0]):
+        raise ValueError("pre must have one entry per row of x")
+    if post is not None and (_req(post, torch.float32, "post", 1).numel() != n):
+        raise ValueError("post must have one entry per output row")
+    if self_mode and x.shape[0] != n:
+        raise ValueError("self term needs a square operator")
+    y = torch.empty(n, x.shape[1], dtype=torch.float32, device=x.device)
+    check(_lib.lib().ocn_spmm_csr(ptr(rowptr), ptr(col), n, ptr(x), x.shape[1], ptr(pre), ptr(post),
+                                  SPMM_MODES[mode], int(edge_scale), int(self_mode), ptr(y), stream_ptr()),
+          "ocn_spmm_csr")
+    return y
+
+
+def deg_rsqrt(rowptr: Tensor, add: float = 1.0) -> Tensor:
+    _req(rowptr, torch.int64, "rowptr", 1)
+    n = rowptr.numel() - 1
+    out = torch.empty(n, dtype=torch.float32, device=rowptr.device)
+    check(_lib.lib().ocn_deg_rsqrt(ptr(rowptr), n, float(add), ptr(out), stream_ptr()), "ocn_deg_rsqrt")
+    return out
+
+
+def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int):
+    """CSR pattern of A·B (columns ascending).  One host sync for the output size."""
+    _req(rowptrA, torch.int64, "rowptrA", 1); _req(colA, torch.int32, "colA", 1)
+    _req(rowptrB, torch.int64, "rowptrB", 1); _req(colB, torch.int32, "colB", 1)
+    l = _lib.lib()
+    if n_cols_b > l.ocn_spgemm_max_cols():
+        raise NotImplementedError(f"A·B pattern with {n_cols_b} columns exceeds the LDS bitmap "
+                                  f"({l.ocn_spgemm_max_cols()}); the reference does not form A² at "
+                                  "that size either (it uses the per-batch walk-count route)")
+    n = rowptrA.numel() - 1
+    dev = colA.device
+    cnt = torch.empty(n, dtype=torch.int32, device=dev)
+    check(l.ocn_spgemm_pattern_count(ptr(rowptrA), ptr(colA), n, ptr(rowptrB), ptr(colB), n_cols_b,
+                                     ptr(cnt), stream_ptr()), "ocn_spgemm_pattern_count")
+    rowptrC = scan_i32(cnt)
+    nnz = int(rowptrC[-1].item())
+    colC = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
+    if nnz:
+        check(l.ocn_spgemm_pattern_fill(ptr(rowptrA), ptr(colA), n, ptr(rowptrB), ptr(colB), n_cols_b,
+                                        ptr(rowptrC), ptr(colC), stream_ptr()), "ocn_spgemm_pattern_fill")
+    return rowptrC, colC

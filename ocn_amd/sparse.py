@@ -1,0 +1,259 @@
+"""Adjacency container with the torch_sparse.SparseTensor surface the OCN drivers touch.
+
+The reference keeps adjacencies as ``torch_sparse.SparseTensor`` (int64 row/col) and calls on
+it: ``from_edge_index``, ``to_device``, ``to_symmetric``, ``to_torch_sparse_coo_tensor``,
+``from_torch_sparse_coo_tensor``, ``sizes``, ``device`` (NeighborOverlap_large.py:51-74,103-119),
+``__getitem__``, ``storage.row/col/rowcount``, ``csr``, ``coo``, ``sparse_sizes``,
+``fill_value_``, ``coalesce``, ``to_dense``, ``from_dense`` (utils.py:42-44,150-158,256-257,
+302-321), ``sum(dim)``, ``mul``, ``size`` (model.py:2261-2276).  This class offers those names
+over the layout the HIP kernels want: int64 rowptr + int32 col (columns ascending in a row)
+resident in HBM.  Format conversions (sort, unique) are torch ops; arithmetic is in the HIP
+library.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+
+
+class _Storage:
+    def __init__(self, owner: "SparseTensor"):
+        self._o = owner
+
+    def row(self) -> Tensor:
+        return self._o._row64()
+
+    def col(self) -> Tensor:
+        return self._o._col.to(torch.int64)
+
+    def rowptr(self) -> Tensor:
+        return self._o._rowptr
+
+    def rowcount(self) -> Tensor:
+        return self._o._rowptr[1:] - self._o._rowptr[:-1]
+
+    def value(self) -> Optional[Tensor]:
+        return self._o._value
+
+    def has_value(self) -> bool:
+        return self._o._value is not None
+
+
+class SparseTensor:
+    def __init__(self, row: Optional[Tensor] = None, rowptr: Optional[Tensor] = None,
+                 col: Optional[Tensor] = None, value: Optional[Tensor] = None,
+                 sparse_sizes: Optional[Tuple[int, int]] = None, is_sorted: bool = False,
+                 trust_data: bool = False):
+        assert col is not None and (row is not None or rowptr is not None)
+        if sparse_sizes is None:
+            n_rows = (int(row.max()) + 1 if row.numel() else 0) if rowptr is None else rowptr.numel() - 1
+            n_cols = int(col.max()) + 1 if col.numel() else 0
+            sparse_sizes = (n_rows, n_cols)
+        self._sizes = (int(sparse_sizes[0]), int(sparse_sizes[1]))
+        if rowptr is None:
+            row = row.to(torch.int64)
+            col64 = col.to(torch.int64)
+            if not is_sorted:
+                perm = torch.argsort(row * max(self._sizes[1], 1) + col64, stable=True)
+                row, col64 = row[perm], col64[perm]
+                if value is not None:
+                    value = value[perm]
+            if not trust_data and row.numel():
+                if int(row.min()) < 0 or int(row.max()) >= self._sizes[0] or int(col64.min()) < 0 \
+                        or int(col64.max()) >= self._sizes[1]:
+                    raise IndexError("SparseTensor: index out of range for sparse_sizes")
+            cnt = torch.bincount(row, minlength=self._sizes[0])
+            rowptr = torch.zeros(self._sizes[0] + 1, dtype=torch.int64, device=col.device)
+            torch.cumsum(cnt, 0, out=rowptr[1:])
+            col = col64
+        self._rowptr = rowptr.to(torch.int64).contiguous()
+        self._col = col.to(torch.int32).contiguous()
+        self._value = None if value is None else value.contiguous()
+        self._row_cache: Optional[Tensor] = None
+        self._maxdeg: Optional[int] = None
+        self.storage = _Storage(self)
+
+    # ---- constructors ------------------------------------------------------------------
+    @classmethod
+    def from_edge_index(cls, edge_index: Tensor, edge_attr: Optional[Tensor] = None,
+                        sparse_sizes: Optional[Tuple[int, int]] = None, is_sorted: bool = False,
+                        trust_data: bool = False) -> "SparseTensor":
+        return cls(row=edge_index[0], col=edge_index[1], value=edge_attr, sparse_sizes=sparse_sizes,
+                   is_sorted=is_sorted, trust_data=trust_data)
+
+    @classmethod
+    def from_csr(cls, rowptr: Tensor, col: Tensor, sparse_sizes, value: Optional[Tensor] = None):
+        return cls(rowptr=rowptr, col=col, value=value, sparse_sizes=sparse_sizes)
+
+    @classmethod
+    def from_dense(cls, mat: Tensor) -> "SparseTensor":
+        r, c = mat.nonzero(as_tuple=True)
+        return cls(row=r, col=c, value=mat[r, c], sparse_sizes=tuple(mat.shape), is_sorted=True,
+                   trust_data=True)
+
+    @classmethod
+    def from_torch_sparse_coo_tensor(cls, mat, has_value: bool = True) -> "SparseTensor":
+        if isinstance(mat, CooView):
+            sp = mat.sp
+            if has_value and sp._value is None:
+                if mat.is_product:
+                    raise NotImplementedError(
+                        "walk-count values of A@A are not formed; the reference drops them "
+                        "(from_torch_sparse_coo_tensor(spadj @ spadj, False), "
+                        "NeighborOverlap_large.py:74,119)")
+                return sp.fill_value(1.0)
+            return sp if has_value or sp._value is None else sp.set_value(None)
+        mat = mat.coalesce()
+        r, c = mat.indices()
+        return cls(row=r, col=c, value=mat.values() if has_value else None,
+                   sparse_sizes=tuple(mat.shape), is_sorted=True, trust_data=True)
+
+    # ---- basic accessors ---------------------------------------------------------------
+    def sizes(self) -> List[int]:
+        return list(self._sizes)
+
+    def sparse_sizes(self) -> Tuple[int, int]:
+        return self._sizes
+
+    def size(self, dim: int) -> int:
+        return self._sizes[dim]
+
+    def nnz(self) -> int:
+        return int(self._col.numel())
+
+    def device(self):
+        return self._col.device
+
+    def has_value(self) -> bool:
+        return self._value is not None
+
+    def csr(self):
+        return self._rowptr, self._col.to(torch.int64), self._value
+
+    def coo(self):
+        return self._row64(), self._col.to(torch.int64), self._value
+
+    def _row64(self) -> Tensor:
+        if self._row_cache is None:
+            deg = self._rowptr[1:] - self._rowptr[:-1]
+            self._row_cache = torch.repeat_interleave(
+                torch.arange(self._sizes[0], device=self._col.device), deg, output_size=self.nnz())
+        return self._row_cache
+
+    def max_rowcount(self) -> int:
+        if self._maxdeg is None:
+            self._maxdeg = int((self._rowptr[1:] - self._rowptr[:-1]).max()) if self._sizes[0] else 0
+        return self._maxdeg
+
+    # ---- device movement ---------------------------------------------------------------
+    def to_device(self, device, non_blocking: bool = False) -> "SparseTensor":
+        out = SparseTensor(rowptr=self._rowptr.to(device, non_blocking=non_blocking),
+                           col=self._col.to(device, non_blocking=non_blocking),
+                           value=None if self._value is None else self._value.to(device, non_blocking=non_blocking),
+                           sparse_sizes=self._sizes)
+        out._maxdeg = self._maxdeg
+        return out
+
+    def to(self, device, non_blocking: bool = False):
+        return self.to_device(device, non_blocking)
+
+    def cuda(self):
+        return self.to_device("cuda")
+
+    def cpu(self):
+        return self.to_device("cpu")
+
+    # ---- structure ops -----------------------------------------------------------------
+    def set_value(self, value: Optional[Tensor]) -> "SparseTensor":
+        out = SparseTensor(rowptr=self._rowptr, col=self._col, value=value, sparse_sizes=self._sizes)
+        out._row_cache, out._maxdeg = self._row_cache, self._maxdeg
+        return out
+
+    def fill_value(self, v: float, dtype=torch.float32) -> "SparseTensor":
+        return self.set_value(torch.full((self.nnz(),), v, dtype=dtype, device=self._col.device))
+
+    def fill_value_(self, v: float, dtype=torch.float32) -> "SparseTensor":
+        self._value = torch.full((self.nnz(),), v, dtype=dtype, device=self._col.device)
+        return self
+
+    def coalesce(self, reduce: str = "sum") -> "SparseTensor":
+        n = max(self._sizes[1], 1)
+        key = self._row64() * n + self._col.to(torch.int64)
+        if self._value is None:
+            ukey = torch.unique_consecutive(key)
+            val = None
+        else:
+            ukey, inv = torch.unique_consecutive(key, return_inverse=True)
+            val = torch.zeros(ukey.numel(), dtype=self._value.dtype, device=key.device).index_add_(0, inv, self._value)
+        return SparseTensor(row=torch.div(ukey, n, rounding_mode="floor"), col=ukey % n, value=val,
+                            sparse_sizes=self._sizes, is_sorted=True, trust_data=True)
+
+    def to_symmetric(self, reduce: str = "sum") -> "SparseTensor":
+        """Pattern of A ∪ Aᵀ, coalesced (values, if any, summed)."""
+        r, c = self._row64(), self._col.to(torch.int64)
+        v = None if self._value is None else torch.cat([self._value, self._value])
+        return SparseTensor(row=torch.cat([r, c]), col=torch.cat([c, r]), value=v,
+                            sparse_sizes=self._sizes, trust_data=True).coalesce(reduce)
+
+    def __getitem__(self, idx: Tensor) -> "SparseTensor":
+        """Row select (utils.py:256-257): row e of the result is row idx[e]."""
+        idx = idx.to(torch.int64)
+        start = self._rowptr[idx]
+        deg = self._rowptr[idx + 1] - start
+        optr = torch.zeros(idx.numel() + 1, dtype=torch.int64, device=idx.device)
+        torch.cumsum(deg, 0, out=optr[1:])
+        total = int(optr[-1])
+        row = torch.repeat_interleave(torch.arange(idx.numel(), device=idx.device), deg, output_size=total)
+        pos = torch.arange(total, device=idx.device) - optr[:-1][row] + start[row]
+        return SparseTensor(rowptr=optr, col=self._col[pos],
+                            value=None if self._value is None else self._value[pos],
+                            sparse_sizes=(idx.numel(), self._sizes[1]))
+
+    def to_dense(self) -> Tensor:
+        d = torch.zeros(self._sizes, device=self._col.device)
+        v = self._value if self._value is not None else torch.ones(self.nnz(), device=self._col.device)
+        d.index_put_((self._row64(), self._col.to(torch.int64)), v.to(d.dtype), accumulate=True)
+        return d
+
+    def sum(self, dim: int) -> Tensor:
+        v = self._value if self._value is not None else torch.ones(self.nnz(), device=self._col.device)
+        idx = self._col.to(torch.int64) if dim == 0 else self._row64()
+        return torch.zeros(self._sizes[1 - dim] if dim in (0, 1) else 0, dtype=v.dtype,
+                           device=v.device).index_add_(0, idx, v)
+
+    def to_torch_sparse_coo_tensor(self) -> "CooView":
+        return CooView(self)
+
+    def __repr__(self) -> str:
+        return f"SparseTensor(sizes={self._sizes}, nnz={self.nnz()}, device={self.device()})"
+
+
+class CooView:
+    """What ``adj.to_torch_sparse_coo_tensor()`` hands back.  The only thing the drivers do with it
+    is ``spadj @ spadj`` followed by ``SparseTensor.from_torch_sparse_coo_tensor(.., False)``
+    (NeighborOverlap_large.py:68-74,112-119); ``@`` runs the HIP A·B pattern kernels."""
+
+    def __init__(self, sp: SparseTensor, is_product: bool = False):
+        self.sp = sp
+        self.is_product = is_product
+
+    @property
+    def shape(self):
+        return tuple(self.sp._sizes)
+
+    def __matmul__(self, other: "CooView") -> "CooView":
+        a, b = self.sp, other.sp
+        if a._sizes[1] != b._sizes[0]:
+            raise ValueError("shape mismatch in sparse @ sparse")
+        rowptr, col = ops.spgemm_pattern(a._rowptr, a._col, b._rowptr, b._col, b._sizes[1])
+        return CooView(SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(a._sizes[0], b._sizes[1])),
+                       is_product=True)
+
+    def to_torch(self) -> Tensor:
+        sp = self.sp
+        v = sp._value if sp._value is not None else torch.ones(sp.nnz(), device=sp.device())
+        return torch.sparse_coo_tensor(torch.stack([sp._row64(), sp._col.to(torch.int64)]), v, sp._sizes)

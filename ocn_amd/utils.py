@@ -1,0 +1,159 @@
+"""Drop-in for the hot-path names of the reference's ``utils.py``.
+
+``adjoverlap`` (utils.py:248-285), ``PermIterator`` (utils.py:8-36), ``sparse_tensor_multiply`` /
+``block_matrix_multiply`` (utils.py:287-329) keep their signatures.  ``adjoverlap`` returns a lazy
+:class:`CNBatch` instead of a materialised [B, N] SparseTensor; the predictors in
+``ocn_amd.model`` recognise it and run the fused HIP path, ``.materialize()`` yields the explicit
+matrix (values 1.0) for inspection and parity tests.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from . import ops
+from .sparse import SparseTensor
+
+
+class PermIterator:
+    """Batch index iterator (utils.py:8-36): ``randperm`` + drop-last when training, ``arange`` +
+    ragged tail kept in eval."""
+
+    def __init__(self, device, size, bs, training=True) -> None:
+        self.bs = bs
+        self.training = training
+        self.idx = torch.randperm(size, device=device) if training else torch.arange(size, device=device)
+
+    def __len__(self):
+        return (self.idx.shape[0] + (self.bs - 1) * (not self.training)) // self.bs
+
+    def __iter__(self):
+        self.ptr = 0
+        return self
+
+    def __next__(self):
+        if self.ptr + self.bs * self.training > self.idx.shape[0]:
+            raise StopIteration
+        ret = self.idx[self.ptr:self.ptr + self.bs]
+        self.ptr += self.bs
+        return ret
+
+
+class CNState:
+    """Device state of one candidate batch after the intersection kernel: where each batch row
+    starts (``off``), one flag byte per neighbour of the source node, the per-column histograms
+    {n1, n2, n_union}, and the integer CN counts."""
+
+    def __init__(self, adj: SparseTensor, t1: SparseTensor, t2: Optional[SparseTensor], tarei: Tensor):
+        if tarei.dim() != 2 or tarei.shape[0] != 2:
+            raise ValueError("tarei must be [2, B]")
+        if t1.sparse_sizes() != adj.sparse_sizes() or (t2 is not None and t2.sparse_sizes() != adj.sparse_sizes()):
+            raise ValueError("adjoverlap: adjacency sizes differ")        # utils.py:164 assert
+        self.adj = adj
+        self.src = tarei[0].to(torch.int64).contiguous()
+        self.dst = tarei[1].to(torch.int64).contiguous()
+        self.B = self.src.numel()
+        self.N = adj.size(1)
+        ops.check_edges(self.src, self.dst, adj.size(0), t1.size(0))
+        self.off, self.flags, self.hist, self.cnt1, self.cnt2, self.status = ops.cn_flags(
+            adj._rowptr, adj._col, (t1._rowptr, t1._col),
+            None if t2 is None else (t2._rowptr, t2._col), self.src, self.dst, self.N,
+            adj.max_rowcount())
+        self._hist_live = True
+
+    def check_status(self) -> None:
+        if int(self.status.item()) != 0:
+            raise RuntimeError("CN flag buffer capacity exceeded")
+
+    def weights_cn5(self, innerprod: Tensor) -> Tensor:
+        assert self._hist_live, "histogram already consumed"
+        self._hist_live = False
+        return ops.cn_weights_cn5(self.hist, innerprod)
+
+    def weights_cn7(self, sum_fill: float) -> Tensor:
+        assert self._hist_live, "histogram already consumed"
+        self._hist_live = False
+        return ops.cn_weights_cn7(self.hist, sum_fill)
+
+    def gather(self, weights: Tensor, h: Tensor):
+        return ops.cn_gather(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off,
+                             self.flags, weights, h)
+
+    def materialize(self, bit: int) -> SparseTensor:
+        """[B, N] matrix of the entries whose flag has ``bit`` set, values 1.0 (host-side format
+        conversion for tests; not on the product path)."""
+        row_sel = self.adj[self.src]
+        r, c, _ = row_sel.coo()
+        order_off = row_sel._rowptr[:-1]
+        pos = torch.arange(r.numel(), device=r.device) - order_off[r] + self.off[:-1][r]
+        keep = (self.flags[pos] & bit) != 0
+        return SparseTensor(row=r[keep], col=c[keep],
+                            value=torch.ones(int(keep.sum()), device=r.device),
+                            sparse_sizes=(self.B, self.N), is_sorted=True, trust_data=True)
+
+
+class CNBatch:
+    """Lazy ``adjoverlap(adj1, adj2, tarei)``: rows N_adj1(tarei[0][e]) ∩ N_adj2(tarei[1][e])."""
+
+    def __init__(self, adj1: SparseTensor, adj2: SparseTensor, tarei: Tensor):
+        self.adj1, self.adj2, self.tarei = adj1, adj2, tarei
+        self._state: Optional[CNState] = None
+
+    def sizes(self):
+        return [self.tarei.shape[1], self.adj1.size(1)]
+
+    def size(self, dim: int) -> int:
+        return self.sizes()[dim]
+
+    def device(self):
+        return self.adj1.device()
+
+    def _single(self) -> CNState:
+        if self._state is None:
+            self._state = CNState(self.adj1, self.adj2, None, self.tarei)
+        return self._state
+
+    def counts(self) -> Tensor:
+        """Integer CN count per candidate edge (per-row nnz of the reference's result)."""
+        return self._single().cnt1
+
+    def materialize(self) -> SparseTensor:
+        return self._single().materialize(1)
+
+
+def fuse(cn1: CNBatch, cn2: CNBatch, tar_ei: Tensor) -> CNState:
+    """One intersection pass for the (cn1, cn2) pair every driver builds from the same candidate
+    edges (NeighborOverlap_large.py:76-82,121-159)."""
+    if not isinstance(cn1, CNBatch) or not isinstance(cn2, CNBatch):
+        raise TypeError("ocn_amd predictors take the CNBatch handles returned by ocn_amd.utils.adjoverlap")
+    if cn1.adj1 is not cn2.adj1:
+        raise NotImplementedError("cn1 and cn2 must select their source rows from the same adjacency")
+    if cn1.tarei.shape != cn2.tarei.shape or cn1.tarei.shape != tar_ei.shape:
+        raise ValueError("cn1, cn2 and tar_ei describe different numbers of candidate edges")
+    if ops.validate_indices and not (torch.equal(cn1.tarei, cn2.tarei) and torch.equal(cn1.tarei, tar_ei)):
+        raise NotImplementedError("cn1, cn2 and tar_ei must be built from the same candidate edges")
+    return CNState(cn1.adj1, cn1.adj2, cn2.adj2, cn1.tarei)
+
+
+def adjoverlap(adj1: SparseTensor, adj2: SparseTensor, tarei: Tensor, filled1: bool = False,
+               calresadj: bool = False, cnsampledeg: int = -1, ressampledeg: int = -1) -> CNBatch:
+    """utils.py:248-285.  ``calresadj`` / sampling belong to the cn2-cn4 predictors, which no
+    reference driver can call."""
+    if calresadj or cnsampledeg > 0 or ressampledeg > 0:
+        raise NotImplementedError("calresadj / neighbour sampling are outside the cn5/cn7 path")
+    return CNBatch(adj1, adj2, tarei)
+
+
+def block_matrix_multiply(spadj: SparseTensor, block_size: int) -> SparseTensor:
+    """utils.py:287-323: A·A for the dense ddi graph.  Returns the offset-correct pattern of A²
+    (the reference's tile accumulation drops the (i, j) offsets); values are not
+    formed because ``adjoverlap`` discards them (utils.py:150-151)."""
+    return SparseTensor.from_torch_sparse_coo_tensor(
+        spadj.to_torch_sparse_coo_tensor() @ spadj.to_torch_sparse_coo_tensor(), False)
+
+
+def sparse_tensor_multiply(spadj: SparseTensor, block_size: int = 1024) -> SparseTensor:
+    """utils.py:326-329."""
+    return block_matrix_multiply(spadj, block_size)

@@ -1,0 +1,329 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): integer CN counts and patterns bit-exact; fp32 pooled vectors and
+scores within 1e-5 (atol) + 1e-5 (rtol).
+"""
+import json
+import os
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from oracle import ocn_oracle as O
+from tests.helpers import batch, close, make_graph, product_adj2, spm_equal, to_product
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+CASES = [  # n, avg_deg, max_deg, B, seed, isolated
+    (64, 5, 20, 37, 0, 3),
+    (500, 8, 100, 300, 1, 10),
+    (3000, 12, 400, 2048, 2, 0),
+    (20000, 10, 600, 8192, 3, 100),
+]
+
+
+@pytest.fixture(scope="module", params=CASES, ids=lambda c: f"n{c[0]}_B{c[3]}")
+def case(request, hiplib):
+    n, avg, mx, B, seed, iso = request.param
+    oadj = make_graph(n, avg, mx, seed, isolated=iso)
+    oadj2 = O.adj2_sparse(oadj)
+    e = batch(oadj, B, seed + 50)
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    return SimpleNamespace(n=n, B=B, seed=seed, oadj=oadj, oadj2=oadj2, e=e, adj=adj, adj2=adj2,
+                           ocn1=O.adjoverlap(oadj, oadj, e), ocn2=O.adjoverlap(oadj, oadj2, e))
+
+
+def test_adj2_pattern_bit_exact(case):
+    assert case.adj2.nnz() == case.oadj2.nnz
+    assert spm_equal(case.adj2, case.oadj2)
+
+
+def test_adjoverlap_counts_and_pattern_bit_exact(case):
+    from ocn_amd.utils import adjoverlap
+    e = case.e.to(DEV)
+    h1, h2 = adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e)
+    assert h1.counts().cpu().tolist() == torch.bincount(case.ocn1.row, minlength=case.B).tolist()
+    assert h2.counts().cpu().tolist() == torch.bincount(case.ocn2.row, minlength=case.B).tolist()
+    assert spm_equal(h1.materialize(), case.ocn1)
+    assert spm_equal(h2.materialize(), case.ocn2)
+    assert h1.sizes() == [case.B, case.n]
+
+
+def test_fused_flags_histograms(case):
+    from ocn_amd.utils import CNState
+    st = CNState(case.adj, case.adj, case.adj2, case.e.to(DEV))
+    st.check_status()
+    assert st.cnt1.cpu().tolist() == torch.bincount(case.ocn1.row, minlength=case.B).tolist()
+    assert st.cnt2.cpu().tolist() == torch.bincount(case.ocn2.row, minlength=case.B).tolist()
+    hist = st.hist.cpu()
+    assert hist[:, 0].tolist() == torch.bincount(case.ocn1.col, minlength=case.n).tolist()
+    assert hist[:, 1].tolist() == torch.bincount(case.ocn2.col, minlength=case.n).tolist()
+    union = torch.unique(torch.cat([O.spm2elem(case.ocn1), O.spm2elem(case.ocn2)]))
+    assert hist[:, 2].tolist() == torch.bincount(union & 0xFFFFFFFF, minlength=case.n).tolist()
+    assert spm_equal(st.materialize(1), case.ocn1) and spm_equal(st.materialize(2), case.ocn2)
+    assert int(st.off[-1]) == int(case.oadj.rowcount()[case.e[0]].sum())
+
+
+@pytest.mark.parametrize("H", [32, 64, 256, 48])
+@pytest.mark.parametrize("ip", [0.0, 0.37])
+def test_cn5_pool(case, H, ip):
+    from ocn_amd.utils import CNState
+    g = torch.Generator().manual_seed(case.seed)
+    x = torch.randn(case.n, H, generator=g)
+    xcn1, xcn2, aux = O.cn5_pool(x, case.ocn1, case.ocn2, torch.tensor([ip]))
+    st = CNState(case.adj, case.adj, case.adj2, case.e.to(DEV))
+    w = st.weights_cn5(torch.tensor([ip], device=DEV))
+    g1, g2, gij = st.gather(w, x.to(DEV))
+    # column weights: w1 = 1/S1 is exact; the cn2 weights inherit S2's conditioning when ip != 0
+    cols1 = torch.unique(case.ocn1.col)
+    assert torch.equal(w[:, 0].cpu()[cols1], aux["inv1"][cols1])
+    assert torch.equal(gij.cpu(), x[case.e[0]] * x[case.e[1]])
+    if ip == 0.0:
+        assert torch.equal(g1.cpu(), xcn1), "ncn1 pooling is order- and rounding-exact"
+        assert close(g2, xcn2)
+    else:
+        assert close(g1, xcn1)
+        # S2 cancels near nip: compare relative to the magnitude the reference's own fp32 sum carries
+        scale = max(1.0, xcn2.abs().max().item())
+        assert (g2.cpu() - xcn2).abs().max().item() <= 2e-4 * scale
+
+
+@pytest.mark.parametrize("sum_fill", [0.0, 1.0, 2.74])
+def test_cn7_pool(case, sum_fill):
+    from ocn_amd.utils import CNState
+    H = 64
+    x = torch.randn(case.n, H, generator=torch.Generator().manual_seed(7))
+    xcn1, xcn2, _ = O.cn7_pool(x, case.ocn1, case.ocn2, sum_fill)
+    st = CNState(case.adj, case.adj, case.adj2, case.e.to(DEV))
+    g1, g2, _ = st.gather(st.weights_cn7(sum_fill), x.to(DEV))
+    assert torch.equal(g1.cpu(), xcn1)
+    assert torch.equal(g2.cpu(), xcn2)
+
+
+@pytest.mark.parametrize("name,ln,tailact,two", [("cn5", True, True, False), ("cn5", False, False, True),
+                                                 ("cn7", True, True, False)])
+def test_predictor_scores(case, name, ln, tailact, two):
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    H = 64
+    torch.manual_seed(case.seed)
+    x = torch.randn(case.n, H)
+    pred = predictor_dict[name](H, H, 1, 3, 0.05, 0.4, ln, use_xlin=True, tailact=tailact,
+                                twolayerlin=two, beta=1.0).eval()
+    sd = {k: v.detach().clone() for k, v in pred.state_dict().items()}
+    args = SimpleNamespace(sum=2.74)
+    if name == "cn5":
+        ref = O.cn5_forward(sd, x, case.ocn1, case.ocn2, case.e, ln, tailact, two)
+    else:
+        ref = O.cn7_forward(sd, x, case.ocn1, case.ocn2, case.e, args.sum, ln, tailact, two)
+    e = case.e.to(DEV)
+    with torch.no_grad():
+        out = pred.to(DEV)(x.to(DEV), case.adj, adjoverlap(case.adj, case.adj, e),
+                           adjoverlap(case.adj, case.adj2, e), e, args)
+    assert out.shape == (case.B, 1) and out.dtype == torch.float32
+    assert close(out, ref), (out.cpu() - ref).abs().max()
+
+
+def test_predictor_train_mode_refuses_backward(case):
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    pred = predictor_dict["cn5"](16, 16, 1, 3, 0.0).to(DEV).train()
+    e = case.e.to(DEV)
+    x = torch.randn(case.n, 16, device=DEV)
+    with pytest.raises(NotImplementedError):
+        pred.multidomainforward(x, case.adj, adjoverlap(case.adj, case.adj, e),
+                                adjoverlap(case.adj, case.adj2, e), e)
+
+
+# ---- golden: hand-derived Appendix C --------------------------------------------------------
+def test_appendix_c_on_gpu(hiplib):
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import CNState
+    g = json.load(open(os.path.join(GOLD, "appendix_c.json")))["path_graph"]
+    und = torch.tensor(g["undirected_edges"]).t()
+    adj = SparseTensor.from_edge_index(und.to(DEV), sparse_sizes=(4, 4)).to_symmetric()
+    adj2 = product_adj2(adj)
+    r, c, _ = adj2.coo()
+    rows = {str(i): c[r == i].cpu().tolist() for i in range(4)}
+    assert rows == g["a2_rows"]
+    e = torch.tensor(g["batch"]).t().contiguous().to(DEV)
+    st = CNState(adj, adj, adj2, e)
+    assert st.cnt1.cpu().tolist() == g["cn1_counts"] and st.cnt2.cpu().tolist() == g["cn2_counts"]
+    assert st.hist[:, 0].cpu().tolist() == g["S1"] and st.hist[:, 1].cpu().tolist() == g["cn2_colsum"]
+    eye = torch.eye(4, device=DEV).repeat(1, 4).contiguous()           # H = 16, h[k] = one-hot(k) x4
+    for key, ip in (("cn5_innerprod_0", 0.0), ("cn5_innerprod_0.37", 0.37)):
+        st = CNState(adj, adj, adj2, e)
+        w = st.weights_cn5(torch.tensor([ip], device=DEV))
+        _, g2, _ = st.gather(w, eye)
+        dense = g2[:, :4].cpu()                                        # row e = ncn2[e, :]
+        got = [dense[r_, c_].item() for r_, c_ in g["union_pattern"]]
+        assert got == pytest.approx(g[key]["ncn2"], rel=2e-6, abs=1e-7)
+    # Q2: a column hit by exactly one edge of the batch is zeroed in cn5
+    st = CNState(adj, adj, adj2, torch.tensor([[0], [1]], device=DEV))
+    w = st.weights_cn5(torch.tensor([0.0], device=DEV))
+    assert w[2, 0].item() == 0.0
+    g1, _, _ = st.gather(w, eye)
+    assert g1.abs().max().item() == 0.0
+
+
+def test_oracle_vectors_regression(hiplib):
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import CNState
+    for rec in json.load(open(os.path.join(GOLD, "oracle_vectors.json"))):
+        n, H = rec["n"], rec["H"]
+        ei = torch.tensor(rec["edge_index"])
+        adj = SparseTensor.from_edge_index(ei.to(DEV), sparse_sizes=(n, n)).to_symmetric()
+        adj2 = product_adj2(adj)
+        assert adj2.nnz() == rec["a2_nnz"]
+        e = torch.tensor(rec["batch"]).to(DEV)
+        x = torch.randn(n, H, generator=torch.Generator().manual_seed(rec["x_seed"])).to(DEV)
+        st = CNState(adj, adj, adj2, e)
+        assert st.cnt1.cpu().tolist() == rec["cn1_counts"] and st.cnt2.cpu().tolist() == rec["cn2_counts"]
+        g1, g2, _ = st.gather(st.weights_cn5(torch.tensor([0.0], device=DEV)), x)
+        assert g1[0].cpu().tolist() == pytest.approx(rec["cn5_ip0.0"]["xcn1_row0"], rel=1e-6, abs=1e-6)
+        assert g2[0].cpu().tolist() == pytest.approx(rec["cn5_ip0.0"]["xcn2_row0"], rel=1e-5, abs=1e-6)
+        st = CNState(adj, adj, adj2, e)
+        g1, g2, _ = st.gather(st.weights_cn7(2.74), x)
+        assert g1[0].cpu().tolist() == pytest.approx(rec["cn7_sum2.74"]["xcn1_row0"], rel=1e-6, abs=1e-6)
+        assert g2[0].cpu().tolist() == pytest.approx(rec["cn7_sum2.74"]["xcn2_row0"], rel=1e-6, abs=1e-6)
+
+
+# ---- edge cases ---------------------------------------------------------------------------
+def test_edge_cases(hiplib):
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import CNState, adjoverlap
+    oadj = make_graph(200, 6, 50, 11, isolated=20)
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    oadj2 = O.adj2_sparse(oadj)
+    # empty batch
+    e0 = torch.zeros(2, 0, dtype=torch.long, device=DEV)
+    st = CNState(adj, adj, adj2, e0)
+    g1, g2, gij = st.gather(st.weights_cn5(torch.zeros(1, device=DEV)), torch.randn(200, 32, device=DEV))
+    assert g1.shape == (0, 32) and int(st.off[0]) == 0
+    pred = predictor_dict["cn5"](32, 32, 1, 3, 0.0).to(DEV).eval()
+    with torch.no_grad():
+        out = pred(torch.randn(200, 32, device=DEV), adj, adjoverlap(adj, adj, e0), adjoverlap(adj, adj2, e0), e0)
+    assert out.shape == (0, 1)
+    # isolated endpoints, self pairs, duplicated edges, every edge identical
+    e = torch.tensor([[199, 0, 5, 5, 5, 7, 190], [0, 199, 5, 9, 9, 7, 195]])
+    st = CNState(adj, adj, adj2, e.to(DEV))
+    c1, c2 = O.adjoverlap(oadj, oadj, e), O.adjoverlap(oadj, oadj2, e)
+    assert st.cnt1.cpu().tolist() == torch.bincount(c1.row, minlength=7).tolist()
+    assert st.cnt2.cpu().tolist() == torch.bincount(c2.row, minlength=7).tolist()
+    x = torch.randn(200, 32)
+    r1, r2, _ = O.cn5_pool(x, c1, c2, torch.tensor([0.0]))
+    g1, g2, _ = st.gather(st.weights_cn5(torch.zeros(1, device=DEV)), x.to(DEV))
+    assert close(g1, r1) and close(g2, r2)
+    # out-of-range endpoint -> IndexError like the reference's index_select, not a GPU fault
+    with pytest.raises(IndexError):
+        CNState(adj, adj, adj2, torch.tensor([[0], [200]], device=DEV))
+    # graph with no edges at all
+    from ocn_amd.sparse import SparseTensor
+    empty = SparseTensor.from_edge_index(torch.zeros(2, 0, dtype=torch.long, device=DEV), sparse_sizes=(50, 50))
+    e2 = product_adj2(empty)
+    assert e2.nnz() == 0
+    st = CNState(empty, empty, e2, torch.tensor([[1, 2], [3, 4]], device=DEV))
+    assert st.cnt1.cpu().tolist() == [0, 0]
+
+
+def test_hub_rows_longer_than_a_wave(hiplib):
+    """Star + clique: source rows much longer than 64 and target rows of thousands of entries."""
+    from ocn_amd.utils import CNState
+    n = 3000
+    hub = torch.stack([torch.zeros(n - 1, dtype=torch.long), torch.arange(1, n)])
+    ring = torch.stack([torch.arange(1, n - 1), torch.arange(2, n)])
+    oadj = O.to_symmetric(O.from_edge_index(torch.cat([hub, ring], 1), n))
+    oadj2 = O.adj2_sparse(oadj)
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    assert spm_equal(adj2, oadj2)
+    e = torch.tensor([[0, 0, 5, 17, 2999], [0, 9, 0, 18, 1]])
+    st = CNState(adj, adj, adj2, e.to(DEV))
+    c1, c2 = O.adjoverlap(oadj, oadj, e), O.adjoverlap(oadj, oadj2, e)
+    assert st.cnt1.cpu().tolist() == torch.bincount(c1.row, minlength=5).tolist()
+    assert st.cnt2.cpu().tolist() == torch.bincount(c2.row, minlength=5).tolist()
+    x = torch.randn(n, 256)
+    r1, r2, _ = O.cn5_pool(x, c1, c2, torch.tensor([0.0]))
+    g1, g2, _ = st.gather(st.weights_cn5(torch.zeros(1, device=DEV)), x.to(DEV))
+    assert torch.equal(g1.cpu(), r1) and close(g2, r2)
+
+
+# ---- encoders -----------------------------------------------------------------------------
+ENC = [  # cls, conv_fn, layers, in, hid, ln, res, jk, max_x
+    ("GCN", "puregcn", 1, 40, 64, False, False, True, -1),
+    ("GCN", "puregcn", 3, 40, 64, False, True, False, 500),
+    ("GCN", "gin", 1, 128, 256, True, False, True, -1),
+    ("GCN", "gcn", 2, 32, 32, True, True, True, -1),
+    ("GCN", "puremean", 2, 16, 32, False, True, True, -1),
+    ("GCN", "puremax", 1, 16, 32, False, False, False, -1),
+    ("GCN2", "gcn", 1, 64, 64, True, False, True, 500),
+    ("GCN3", "gcn", 5, 128, 32, True, True, True, -1),
+]
+
+
+@pytest.mark.parametrize("cls,conv,L,fin,hid,ln,res,jk,max_x", ENC, ids=lambda v: str(v))
+def test_encoders(hiplib, cls, conv, L, fin, hid, ln, res, jk, max_x):
+    import ocn_amd.model as M
+    n = 500
+    oadj = make_graph(n, 8, 80, 21, isolated=5)
+    adj = to_product(oadj, DEV)
+    torch.manual_seed(5)
+    enc = getattr(M, cls)(fin, hid, hid, L, 0.1, ln, res, max_x, conv, jk, 0.0, xdropout=0.3,
+                          taildropout=0.2).eval()
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    x = torch.randint(0, max_x + 1, (n,)) if max_x >= 0 else torch.randn(n, fin)
+    ref = O.gcn_forward(sd, x, oadj, num_layers=L, conv_fn=conv, ln=ln, res=res, jk=jk, max_x=max_x,
+                        variant={"GCN": 1, "GCN2": 2, "GCN3": 3}[cls])
+    with torch.no_grad():
+        out = enc.to(DEV)(x.to(DEV), adj)
+    assert close(out, ref, atol=2e-5, rtol=2e-5), (out.cpu() - ref).abs().max()
+
+
+# ---- size-independent properties at the benchmark shape -------------------------------------
+def test_properties_collab_shape(hiplib):
+    """ogbl-collab-shaped graph, B = 65536: sizes the oracle cannot finish in seconds, so the
+    checks are invariants of the domain."""
+    from ocn_amd.synth import dataset_like, sample_edges
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import CNState
+    ei, n, _ = dataset_like("collab", seed=0)
+    adj = SparseTensor.from_edge_index(ei.to(DEV), sparse_sizes=(n, n)).to_symmetric()
+    adj2 = product_adj2(adj)
+    r, c, _ = adj.coo()
+    e = sample_edges(r.cpu(), c.cpu(), n, 65536, seed=1).to(DEV)
+    st = CNState(adj, adj, adj2, e)
+    st.check_status()
+    hist = st.hist.clone()
+    # histogram mass == per-edge counts; union between max and sum
+    assert int(hist[:, 0].sum()) == int(st.cnt1.sum()) and int(hist[:, 1].sum()) == int(st.cnt2.sum())
+    assert bool((hist[:, 2] <= hist[:, 0] + hist[:, 1]).all()) and bool((hist[:, 2] >= torch.maximum(hist[:, 0], hist[:, 1])).all())
+    # cn1 is symmetric in (i, j); counts are invariant under a permutation of the batch
+    st_sw = CNState(adj, adj, adj2, e.flip(0).contiguous())
+    assert torch.equal(st_sw.cnt1, st.cnt1)
+    perm = torch.randperm(e.shape[1], device=DEV)
+    st_p = CNState(adj, adj, adj2, e[:, perm].contiguous())
+    assert torch.equal(st_p.cnt1, st.cnt1[perm]) and torch.equal(st_p.cnt2, st.cnt2[perm])
+    assert torch.equal(st_p.hist, hist)
+    # A² contains A's 2-walk closure: diagonal present for every non-isolated node, symmetric nnz
+    deg = adj.storage.rowcount()
+    r2, c2, _ = adj2.coo()
+    assert int((r2 == c2).sum()) == int((deg > 0).sum())
+    # pooling is linear in h and its column weights sum to S1-normalised mass
+    H = 256
+    h1, h2 = torch.randn(n, H, device=DEV), torch.randn(n, H, device=DEV)
+    w = st.weights_cn5(torch.zeros(1, device=DEV))
+    a1, a2, _ = st.gather(w, h1)
+    b1, b2, _ = st.gather(w, h2)
+    s1, s2, _ = st.gather(w, h1 + h2)
+    assert torch.allclose(s1, a1 + b1, atol=1e-4, rtol=1e-4) and torch.allclose(s2, a2 + b2, atol=1e-4, rtol=1e-4)
+    ones = torch.ones(n, H, device=DEV)
+    o1, o2, _ = st.gather(w, ones)
+    # with h = 1: Σ_e xcn1[e] = #{c : S1[c] >= 2} and Σ_e xcn2[e] = #{c : colsum(cn2)[c] >= 1}
+    k1, k2 = int((hist[:, 0] >= 2).sum()), int((hist[:, 1] >= 1).sum())
+    assert abs(o1[:, 0].double().sum().item() - k1) <= 1e-4 * k1 + 1e-3
+    assert abs(o2[:, 0].double().sum().item() - k2) <= 1e-4 * k2 + 1e-3
