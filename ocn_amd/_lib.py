@@ -43,10 +43,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/ocn_kernels.hip -> ocn_amd/libocn_hip.so for gfx950 (hipcc cross-compiles
     without a GPU)."""
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
-            os.path.getmtime(SRC), os.path.getmtime(os.path.join(INCLUDE, "ocn_hip.h"))):
+            os.path.getmtime(SRC), os.path.getmtime(os.path.join(INCLUDE, "ocn_hip.h")),
+            os.path.getmtime(os.path.abspath(__file__))):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
+           # the reference's CPU kernels round the product and the sum separately; HIP's __fmul_rn /
+           # __fadd_rn are plain * and + and would be contracted into FMAs under the default mode
+           "-ffp-contract=off",
            f"-I{INCLUDE}", "-o", LIB_PATH, SRC]
     if verbose:
         print(" ".join(cmd))

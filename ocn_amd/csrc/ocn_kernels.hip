@@ -640,7 +640,7 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
   if (B < 0 || flags_cap < 0) return OCN_EINVAL;
   if (B == 0) return 0;
   if (!rowptrA || !rowptrT1 || !src || !dst || !off || !hist || !cnt1 || !status) return OCN_EINVAL;
-  if ((rowptrT2 == nullptr) != (colT2 == nullptr)) return OCN_EINVAL;
+  // col pointers may legitimately be NULL for an adjacency with no entries
   const int grid = grid_for((B + OCN_WPB - 1) / OCN_WPB);
   hipStream_t st = (hipStream_t)stream;
   if (rowptrT2)

@@ -1,0 +1,171 @@
+"""CPU suite, part 2: the C-ABI library loads and exports everything include/ocn_hip.h declares,
+and the host-side mirror of the reference interface (names, signatures, state_dict keys, error
+behaviour).  No compute calls — there is no GPU here."""
+import inspect
+import os
+import re
+
+import pytest
+import torch
+
+from oracle import ocn_oracle as O
+from ocn_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "ocn_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ocn_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(hiplib):
+    names = _declared()
+    assert len(names) >= 13
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    for n in names:
+        assert getattr(hiplib, n) is not None
+    assert hiplib.ocn_abi_version() == 1
+    assert hiplib.ocn_scan_workspace_bytes(65536) >= 8 * (65536 // 2048 + 2)
+    assert hiplib.ocn_spgemm_max_cols() >= 1_000_000
+
+
+def test_header_cites_reference_lines():
+    txt = open(os.path.join(ROOT, "include", "ocn_hip.h")).read()
+    for cite in ("utils.py:162-183", "model.py:2261", "model.py:2426-2429", "model.py:42-55",
+                 "NeighborOverlap_large.py:68-74"):
+        assert cite in txt
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.OcnHipError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_product_path_refuses_cpu_tensors(hiplib):
+    from ocn_amd import ops
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import adjoverlap
+    adj = SparseTensor.from_edge_index(torch.tensor([[0, 1], [1, 0]]), sparse_sizes=(3, 3))
+    e = torch.tensor([[0], [1]])
+    pred = predictor_dict["cn5"](8, 8, 1, 3, 0.0).eval()
+    with torch.no_grad(), pytest.raises(_lib.OcnHipError, match="no CPU path"):
+        pred(torch.randn(3, 8), adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj, e), e)
+    with pytest.raises(_lib.OcnHipError):
+        ops.spmm_csr(adj._rowptr, adj._col, torch.randn(3, 16))
+
+
+def test_product_does_not_import_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "ocn_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} references the oracle"
+
+
+def test_perm_iterator_matches_reference_semantics():
+    from ocn_amd.utils import PermIterator
+    it = PermIterator("cpu", 10, 4, training=False)
+    assert len(it) == 3 and [b.tolist() for b in it] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
+    assert [b.tolist() for b in it] == [b.tolist() for b in O.perm_batches(10, 4)]
+    torch.manual_seed(0)
+    it = PermIterator("cpu", 10, 4, training=True)
+    got = [b for b in it]
+    assert len(it) == 2 and len(got) == 2 and all(b.numel() == 4 for b in got)     # drop-last
+    assert len(set(torch.cat(got).tolist())) == 8
+
+
+def test_predictor_signatures_and_state_dict_keys():
+    from ocn_amd.model import predictor_dict
+    assert {"cn5", "cn7"} <= set(predictor_dict)
+    ctor = ["in_channels", "hidden_channels", "out_channels", "num_layers", "dropout", "edrop", "ln",
+            "cndeg", "use_xlin", "tailact", "twolayerlin", "beta"]
+    for name in ("cn5", "cn7"):
+        cls = predictor_dict[name]
+        assert list(inspect.signature(cls.__init__).parameters)[1:] == ctor            # model.py:2173-2185
+        assert list(inspect.signature(cls.forward).parameters)[1:] == ["x", "adj", "cn1", "cn2", "tar_ei", "filled1"]
+    assert list(inspect.signature(predictor_dict["cn5"].multidomainforward).parameters)[1:] == [
+        "x", "adj", "cn1", "cn2", "tar_ei", "filled1", "cndropprobs"]
+    assert list(inspect.signature(predictor_dict["cn7"].multidomainforward).parameters)[1:] == [
+        "x", "adj", "cn1", "cn2", "tar_ei", "args", "filled1", "cndropprobs"]
+
+    def keys(**kw):
+        return set(predictor_dict["cn5"](16, 16, 1, 3, 0.1, 0.0, **kw).state_dict())
+
+    base = keys()
+    lin = lambda p, idx: {f"{p}.{i}.{s}" for i in idx for s in ("weight", "bias")}
+    want = ({"beta", "alpha", "innerprod", "dropadj.ratio"} | lin("xcnlin", (0, 3, 7)) | lin("xcn1lin", (0, 3, 7))
+            | lin("xcn2lin", (0, 3, 7)) | lin("xcn4lin", (0, 3, 7)) | lin("xijlin", (0, 4)) | lin("lin", (0, 8)))
+    assert base == want
+    assert keys(ln=True) == want | lin("xcnlin", (4,)) | lin("xcn1lin", (4,)) | lin("xcn2lin", (4,)) \
+        | lin("xcn4lin", (4,)) | lin("xijlin", (1,)) | lin("lin", (1,))
+    assert keys(tailact=True) == want - lin("xcnlin", (7,)) - lin("xijlin", (4,))
+    assert keys(twolayerlin=True, ln=True) >= lin("lin", (4, 5))
+    assert keys(use_xlin=True) == want | lin("xlin", (0, 3))
+    # same registration order as the reference => same init under the same seed; buffers checkpointed
+    p = predictor_dict["cn7"](8, 8, 1, 3, 0.0, beta=0.33)
+    assert p.beta.item() == pytest.approx(0.33) and p.alpha.tolist() == [1, 1, 1] and p.innerprod.tolist() == [0.0]
+    p.load_state_dict({k: v for k, v in p.state_dict().items() if "xcn4lin" not in k}, strict=False)
+
+
+def test_encoder_state_dict_keys():
+    from ocn_amd.model import GCN, GCN2, GCN3, convdict, convdict2, convdict3
+    names = {"gcn", "gcn_cached", "sage", "gin", "max", "puremax", "puresum", "puremean", "puregcn", "none"}
+    assert set(convdict) == set(convdict2) == set(convdict3) == names
+    sig = list(inspect.signature(GCN.__init__).parameters)[1:]
+    assert sig == ["in_channels", "hidden_channels", "out_channels", "num_layers", "dropout", "ln", "res",
+                   "max_x", "conv_fn", "jk", "edrop", "xdropout", "taildropout", "noinputlin"]
+    g = GCN(128, 256, 256, 1, 0.05, True, False, -1, "gin", True, 0.0, xdropout=0.7, taildropout=0.3)
+    assert set(g.state_dict()) == {"adjdrop.ratio", "jkparams", "convs.0.lin.weight", "convs.0.bias",
+                                   "lins.0.0.weight", "lins.0.0.bias"}
+    g = GCN(1433, 256, 256, 1, 0.05, True, False, -1, "puregcn", True)
+    assert set(g.state_dict()) == {"adjdrop.ratio", "jkparams", "xemb.1.weight", "xemb.1.bias"}
+    g = GCN2(58, 64, 64, 1, 0.0, True, False, 57, "gcn", True)
+    assert set(g.state_dict()) == {"adjdrop.ratio", "jkparams", "xemb.0.weight", "convs.0.lin.0.weight",
+                                   "lins.0.0.weight", "lins.0.0.bias"}
+    g = GCN3(128, 32, 32, 5, 0.28, True, True, -1, "gcn", True)
+    assert {f"convs.{i}.lin.0.weight" for i in range(5)} <= set(g.state_dict())
+    assert "lins.4.0.weight" not in g.state_dict() and "lins.3.0.weight" in g.state_dict()
+
+
+def test_sparse_container_matches_oracle_formats():
+    """Format conversions are plain torch ops and run on CPU: compare with the oracle's SpM."""
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.synth import chung_lu_graph
+    n = 120
+    ei = chung_lu_graph(n, 6, 30, seed=4)
+    dup = torch.cat([ei, ei[:, :10]], dim=1)                       # duplicates + one direction only
+    sp = SparseTensor.from_edge_index(dup, sparse_sizes=(n, n))
+    o = O.from_edge_index(dup, n)
+    assert sp.nnz() == o.nnz and sp.coo()[1].tolist() == o.col.tolist()
+    s, os_ = sp.to_symmetric(), O.to_symmetric(o)
+    assert s.coo()[0].tolist() == os_.row.tolist() and s.coo()[1].tolist() == os_.col.tolist()
+    assert s.sizes() == [n, n] and s.sparse_sizes() == (n, n) and s.size(1) == n
+    idx = torch.tensor([5, 5, 0, n - 1])
+    sel, osel = s[idx], O.row_select(os_, idx)
+    assert sel.coo()[0].tolist() == osel.row.tolist() and sel.coo()[1].tolist() == osel.col.tolist()
+    assert s.storage.rowcount().tolist() == os_.rowcount().tolist()
+    assert s.max_rowcount() == int(os_.rowcount().max())
+    assert torch.equal(s.to_dense(), os_.to_dense())
+    assert torch.equal(s.sum(dim=0), os_.to_dense().sum(0))
+    rt = SparseTensor.from_torch_sparse_coo_tensor(s.to_torch_sparse_coo_tensor(), False)
+    assert rt.coo()[1].tolist() == os_.col.tolist()
+    with pytest.raises(IndexError):
+        SparseTensor.from_edge_index(torch.tensor([[0], [n]]), sparse_sizes=(n, n))
+
+
+def test_adjoverlap_signature_and_unsupported_branches():
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import adjoverlap, sparse_tensor_multiply
+    assert list(inspect.signature(adjoverlap).parameters) == [
+        "adj1", "adj2", "tarei", "filled1", "calresadj", "cnsampledeg", "ressampledeg"]
+    assert list(inspect.signature(sparse_tensor_multiply).parameters) == ["spadj", "block_size"]
+    adj = SparseTensor.from_edge_index(torch.tensor([[0, 1], [1, 0]]), sparse_sizes=(3, 3))
+    h = adjoverlap(adj, adj, torch.tensor([[0, 1], [1, 2]]))
+    assert h.sizes() == [2, 3]
+    with pytest.raises(NotImplementedError):
+        adjoverlap(adj, adj, torch.tensor([[0], [1]]), calresadj=True)

@@ -1,0 +1,123 @@
+"""CPU suite, part 1: the oracle against its only pins — the hand-derived Appendix C answers and the
+independent set-based model.  (The reference holds no tests or golden vectors: "parity unpinned".)"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import naive_model as NM
+from oracle import ocn_oracle as O
+from ocn_amd.synth import chung_lu_graph, sample_edges
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def appc():
+    return json.load(open(os.path.join(GOLD, "appendix_c.json")))
+
+
+def test_smoke_inputs_spmoverlap(appc):
+    s = appc["smoke_inputs"]
+    a1 = O.from_edge_index(torch.tensor(s["adj1"]), s["n"])
+    a2 = O.from_edge_index(torch.tensor(s["adj2"]), s["n"])
+    out = O.spmoverlap_(a1, a2)
+    assert [out.row.tolist(), out.col.tolist()] == s["spmoverlap"]
+    assert out.val.tolist() == s["spmoverlap_values"] and out.val.dtype == torch.float32
+
+
+def test_path_graph_known_answers(appc):
+    g = appc["path_graph"]
+    adj = O.to_symmetric(O.from_edge_index(torch.tensor(g["undirected_edges"]).t(), g["n"]))
+    for i in range(4):
+        assert adj.col[adj.row == i].tolist() == g["rows"][str(i)]
+    a2 = O.adj2_sparse(adj)
+    for i in range(4):
+        assert a2.col[a2.row == i].tolist() == g["a2_rows"][str(i)]
+    e = torch.tensor(g["batch"]).t().contiguous()
+    cn1, cn2 = O.adjoverlap(adj, adj, e), O.adjoverlap(adj, a2, e)
+    assert [cn1.col[cn1.row == r].tolist() for r in range(3)] == g["cn1_rows"]
+    assert [cn2.col[cn2.row == r].tolist() for r in range(3)] == g["cn2_rows"]
+    assert O.col_sum(cn1).tolist() == g["S1"] and O.col_sum(cn2).tolist() == g["cn2_colsum"]
+    x = torch.randn(4, 8)
+    for key, ip in (("cn5_innerprod_0", 0.0), ("cn5_innerprod_0.37", 0.37)):
+        _, _, aux = O.cn5_pool(x, cn1, cn2, torch.tensor([ip]))
+        pat = list(map(list, zip(aux["ncn2"].row.tolist(), aux["ncn2"].col.tolist())))
+        assert pat == g["union_pattern"]
+        assert aux["S2"].tolist() == pytest.approx(g[key]["S2"], rel=1e-6)
+        assert aux["ncn2"].val.tolist() == pytest.approx(g[key]["ncn2"], rel=1e-6, abs=1e-7)
+    assert aux["scale"] == pytest.approx(g["cn5_innerprod_0"]["scale"], rel=1e-7)
+    # Q2: singleton column is zeroed (cn5) / filled with args.sum (cn7)
+    e1 = torch.tensor([[0], [1]])
+    c1, c2 = O.adjoverlap(adj, adj, e1), O.adjoverlap(adj, a2, e1)
+    xc1, _, aux = O.cn5_pool(x, c1, c2, torch.tensor([0.0]))
+    assert aux["inv1"][2].item() == 0.0 and xc1.abs().max().item() == 0.0
+    xc1, _, aux = O.cn7_pool(x, c1, c2, 2.74)
+    assert aux["inv1"][2].item() == pytest.approx(2.74) and torch.allclose(xc1[0], 2.74 * x[2])
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_oracle_vs_naive_model(seed):
+    n, B, H = 150 + 40 * seed, 120, 12
+    ei = chung_lu_graph(n, 7, 50, seed=seed, clique_frac=0.5)
+    adj = O.to_symmetric(O.from_edge_index(ei, n))
+    a2 = O.adj2_sparse(adj)
+    e = sample_edges(adj.row, adj.col, n, B, seed=seed)
+    nb = NM.neighbours(n, ei.t().tolist())
+    nb2 = NM.two_hop(nb)
+    s1, s2 = NM.cn_sets(nb, nb2, e.t().tolist())
+    cn1, cn2 = O.adjoverlap(adj, adj, e), O.adjoverlap(adj, a2, e)
+    assert [c for r in s1 for c in r] == cn1.col.tolist()
+    assert [c for r in s2 for c in r] == cn2.col.tolist()
+    assert sorted((j, k) for j in range(n) for k in nb2[j]) == list(zip(a2.row.tolist(), a2.col.tolist()))
+    x = torch.randn(n, H)
+    for ip in (0.0, 0.37, -1.5):
+        a, b, aux = O.cn5_pool(x, cn1, cn2, torch.tensor([ip]))
+        na, nbb, naux = NM.cn5_pool(n, x.numpy(), s1, s2, ip)
+        assert aux["scale"] == pytest.approx(naux["scale"], rel=1e-6)
+        assert np.abs(a.numpy() - na).max() < 1e-5
+        assert np.abs(b.numpy() - nbb).max() < 1e-4 * max(1.0, np.abs(nbb).max())
+    w = NM.walk_counts(nb, e.t().tolist())
+    c1, c2 = O.get_cn1_cn2(adj, e)
+    assert c1.col.tolist() == cn1.col.tolist()
+    assert [k for r in w for k in r] == c2.col.tolist()
+    assert [v for r in w for v in r.values()] == c2.val.tolist()
+    a, b, _ = O.cn7_pool(x, cn1, c2, 1.0)
+    na, nbb, _ = NM.cn7_pool(n, x.numpy(), s1, w, 1.0)
+    assert np.abs(a.numpy() - na).max() < 1e-5 and np.abs(b.numpy() - nbb).max() < 1e-4
+
+
+def test_adjoverlap_edge_cases():
+    n = 30
+    adj = O.to_symmetric(O.from_edge_index(torch.tensor([[0, 1, 2, 3], [1, 2, 3, 0]]), n))
+    a2 = O.adj2_sparse(adj)
+    empty = torch.zeros(2, 0, dtype=torch.long)
+    out = O.adjoverlap(adj, a2, empty)
+    assert out.nnz == 0 and out.n_rows == 0
+    e = torch.tensor([[29, 0, 0], [0, 29, 0]])             # isolated endpoints, self pair
+    cn1, cn2 = O.adjoverlap(adj, adj, e), O.adjoverlap(adj, a2, e)
+    assert torch.bincount(cn1.row, minlength=3).tolist() == [0, 0, 2]
+    assert torch.bincount(cn2.row, minlength=3).tolist() == [0, 0, 0]     # N(0)∩N²(0): N² of a 4-cycle node = {0, 2}
+    x = torch.randn(n, 4)
+    xc1, xc2, aux = O.cn5_pool(x, cn1, cn2, torch.tensor([0.37]))
+    assert torch.isfinite(xc1).all() and torch.isfinite(xc2).all()
+
+
+def test_adj2_by_block_matches_sparse_and_fold_quirk():
+    n = 70
+    ei = chung_lu_graph(n, 9, 40, seed=9)
+    adj = O.to_symmetric(O.from_edge_index(ei, n))
+    ref = O.adj2_sparse(adj)
+    blk = O.adj2_by_block(adj, block_size=32)
+    assert blk.row.tolist() == ref.row.tolist() and blk.col.tolist() == ref.col.tolist()
+    dense = adj.to_dense()
+    assert torch.equal(blk.to_dense(), dense @ dense)       # walk-count values, offset-correct tiles
+    folded = O.adj2_by_block(adj, block_size=32, fold_quirk=True)
+    assert int(folded.row.max()) < 32 and int(folded.col.max()) < 32
+
+
+def test_perm_batches_keeps_ragged_tail():
+    b = O.perm_batches(10, 4)
+    assert [x.tolist() for x in b] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
