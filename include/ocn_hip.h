@@ -111,6 +111,16 @@ int ocn_spgemm_pattern_fill(const int64_t* rowptrA, const int32_t* colA, int64_t
                             const int64_t* rowptrB, const int32_t* colB, int64_t n_colsB,
                             const int64_t* rowptrC, int32_t* colC, void* stream);
 
+/* Glue between the dense Linear layers of the MLP heads (model.py:2203-2235, 2429-2437), which
+ * stay library GEMMs: y = LayerNorm(x) (eps, affine gamma/beta) followed by ReLU when `relu` != 0,
+ * one pass over [rows][H] (replaces nn.LayerNorm + Dropout(eval) + nn.ReLU); and the branch mix
+ * out = c[0]*x1 + c[1]*x2 + c[2]*x3 with the three coefficients read from device memory
+ * (alpha.sigmoid().cumprod() and beta, model.py:2435-2436).  H in {16..512, power of two}. */
+int ocn_rows_ln_relu(const float* x, const float* gamma, const float* beta, float eps, int32_t relu,
+                     int64_t rows, int32_t H, float* y, void* stream);
+int ocn_combine3(const float* coef, const float* x1, const float* x2, const float* x3, int64_t n,
+                 float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

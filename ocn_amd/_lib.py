@@ -32,6 +32,8 @@ SIGNATURES = {
     "ocn_spgemm_max_cols": (c_int64, []),
     "ocn_spgemm_pattern_count": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P]),
     "ocn_spgemm_pattern_fill": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, _P]),
+    "ocn_rows_ln_relu": (c_int32, [_P, _P, _P, c_float, c_int32, c_int64, c_int32, _P, _P]),
+    "ocn_combine3": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P]),
 }
 
 

@@ -1,0 +1,68 @@
+"""Edge-batch sharding over the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The reference is single-device; this is the new data-parallel layer north_star asks
+for.  The adjacency, A², the embeddings and the weights are replicated; a candidate batch is cut
+into contiguous slices, one per rank.  Because the predictors normalise per column over the WHOLE
+batch (``cn.sum(dim=0)``, model.py:2261,3114), ranks exchange exactly one thing before pooling: the
+int32 per-column histograms {n1, n2, n_union} (sum all-reduce — integer, so exact and
+order-independent; cn5's ``scale`` and S2 are functions of those counts and need no extra
+collective).  Scores come back with one all-gather.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+
+def shard_bounds(total: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced slices (first ``total % world`` ranks get one extra edge)."""
+    base, rem = divmod(total, world)
+    out, s = [], 0
+    for r in range(world):
+        e = s + base + (1 if r < rem else 0)
+        out.append((s, e))
+        s = e
+    return out
+
+
+def allreduce_hist(hist: Tensor, group=None) -> Tensor:
+    """In-place sum of the [N, 4] int32 histograms over the edge shards."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+    return hist
+
+
+def gather_scores(local: Tensor, total: int, group=None) -> Tensor:
+    """All-gather the per-edge scores of every shard back into batch order: [total, C]."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    bounds = shard_bounds(total, world)
+    width = max(e - s for s, e in bounds)
+    pad = local.new_zeros((width,) + tuple(local.shape[1:]))
+    pad[: local.shape[0]] = local
+    out = local.new_empty((world * width,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, pad, group=group)
+    if all(e - s == width for s, e in bounds):
+        return out
+    return torch.cat([out[r * width: r * width + (e - s)] for r, (s, e) in enumerate(bounds)], dim=0)
+
+
+def sharded_predict(predictor, h: Tensor, adj, adj2, edges: Tensor, args=None, group=None) -> Tensor:
+    """Score the global candidate batch ``edges`` [2, B] with the batch cut over the ranks of
+    ``group``; every rank returns the full [B, 1] score vector, equal to the single-device result
+    on the same batch."""
+    from .utils import adjoverlap
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    s, e = shard_bounds(edges.shape[1], world)[rank]
+    mine = edges[:, s:e].contiguous()
+    predictor.set_edge_sharding(group if world > 1 else None, enabled=world > 1)
+    try:
+        local = predictor(h, adj, adjoverlap(adj, adj, mine), adjoverlap(adj, adj2, mine), mine, args)
+    finally:
+        predictor.set_edge_sharding(None, enabled=False)
+    return gather_scores(local, edges.shape[1], group)

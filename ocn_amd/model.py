@@ -269,6 +269,29 @@ class GCN3(_Encoder):
 # ------------------------------------------------------------------------------------------
 # predictors
 # ------------------------------------------------------------------------------------------
+def _seq_eval(seq: nn.Sequential, x: Tensor) -> Tensor:
+    """Eval-mode walk of one of the predictor's ``nn.Sequential`` heads: Dropout/Identity vanish,
+    ``LayerNorm -> ReLU`` becomes one HIP pass (in place on the Linear's fresh output)."""
+    mods = [m for m in seq if not isinstance(m, (nn.Dropout, nn.Identity))]
+    fresh, i = False, 0
+    while i < len(mods):
+        m = mods[i]
+        if (isinstance(m, nn.LayerNorm) and m.elementwise_affine and x.dim() == 2
+                and x.shape[-1] in ops.LN_WIDTHS and x.is_contiguous()):
+            relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+            x = ops.rows_ln_relu(x, m.weight, m.bias, m.eps, relu, inplace=fresh)
+            i += 2 if relu else 1
+        elif isinstance(m, nn.ReLU):
+            x = torch.relu_(x) if fresh else torch.relu(x)
+            i += 1
+        else:
+            x = m(x)
+            i += 1
+        fresh = True
+    return x
+
+
+
 class _CNPredictorBase(nn.Module):
     """Parameters and MLP heads shared by cn5 and cn7 (model.py:2173-2239 ≡ 3023-3089).  The
     ``nn.Sequential`` layouts are part of the checkpoint contract (state_dict keys)."""
@@ -307,6 +330,19 @@ class _CNPredictorBase(nn.Module):
         self.register_parameter("alpha", nn.Parameter(torch.ones((3))))
         self.register_buffer("innerprod", torch.tensor([0.0]))
         self.n = 0
+        self._shard_group, self._sharded = None, False
+
+    def set_edge_sharding(self, group=None, enabled: bool = True) -> None:
+        """The candidate batch handed to ``forward`` is one rank's slice of a global batch: sum the
+        column histograms over ``group`` (RCCL all-reduce) before normalising (ocn_amd.dist)."""
+        self._shard_group, self._sharded = group, enabled
+
+    def _exchange(self, st):
+        if self._sharded:
+            from .dist import allreduce_hist
+            allreduce_hist(st.hist, self._shard_group)
+            ops._mark("allreduce_hist")
+        return st
 
     def _no_backward(self, x: Tensor) -> None:
         if torch.is_grad_enabled() and (x.requires_grad or self.training):
@@ -315,11 +351,19 @@ class _CNPredictorBase(nn.Module):
                 "(autograd for the fused pooling is the next scope row, SURVEY.md §8f-1)")
 
     def _heads(self, x, xcn1, xcn2, xij):
-        xij = self.xijlin(xij)
-        xcn1 = self.xcn1lin(xcn1)
-        xcn2 = self.xcn2lin(xcn2)
         alpha = torch.sigmoid(self.alpha).cumprod(-1)
-        return self.lin(alpha[0] * xcn1 + alpha[1] * xcn2 + self.beta * xij)
+        if self.training or not xij.is_cuda or xij.shape[-1] % 4:
+            xij = self.xijlin(xij)
+            xcn1 = self.xcn1lin(xcn1)
+            xcn2 = self.xcn2lin(xcn2)
+            return self.lin(alpha[0] * xcn1 + alpha[1] * xcn2 + self.beta * xij)
+        # eval: same modules, same parameters; LayerNorm+ReLU and the branch mix run as one HIP
+        # pass each instead of separate elementwise kernels.  The Linear layers stay library GEMMs.
+        xij = _seq_eval(self.xijlin, xij)
+        xcn1 = _seq_eval(self.xcn1lin, xcn1)
+        xcn2 = _seq_eval(self.xcn2lin, xcn2)
+        z = ops.combine3(torch.cat([alpha[:2], self.beta]), xcn1, xcn2, xij)
+        return _seq_eval(self.lin, z)
 
 
 class CNLinkPredictorOringin(_CNPredictorBase):
@@ -329,7 +373,7 @@ class CNLinkPredictorOringin(_CNPredictorBase):
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
         self._no_backward(x)
-        st = fuse(cn1, cn2, tar_ei)
+        st = self._exchange(fuse(cn1, cn2, tar_ei))
         w = st.weights_cn5(self.innerprod)
         xcn1, xcn2, xij = st.gather(w, x.contiguous())
         return self._heads(x, xcn1, xcn2, xij)
@@ -345,7 +389,7 @@ class CNLinkPredictorbaselearn(_CNPredictorBase):
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, args, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
         self._no_backward(x)
-        st = fuse(cn1, cn2, tar_ei)
+        st = self._exchange(fuse(cn1, cn2, tar_ei))
         w = st.weights_cn7(float(args.sum))
         xcn1, xcn2, xij = st.gather(w, x.contiguous())
         return self._heads(x, xcn1, xcn2, xij)

@@ -15,6 +15,12 @@ from ._lib import check, ptr, stream_ptr
 
 FLAGS_NOSYNC_LIMIT = 1 << 30     # bytes of flag buffer we are willing to over-allocate to avoid a host sync
 validate_indices = True          # bounds-check candidate edges on the host side (one sync per batch)
+stage_timer = None               # optional object with .mark(name): bench.py records HIP events between stages
+
+
+def _mark(name: str) -> None:
+    if stage_timer is not None:
+        stage_timer.mark(name)
 
 
 def _req(t: Tensor, dtype, name: str, ndim: Optional[int] = None) -> Tensor:
@@ -76,6 +82,7 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Tuple[Tensor, Tensor], t2: Optio
     _req(src, torch.int64, "src", 1); _req(dst, torch.int64, "dst", 1)
     if dst.numel() != B:
         raise ValueError("src/dst length mismatch")
+    _mark("begin")
     off = edge_offsets(rowptrA, src)
     bound = B * max(int(max_deg_a), 0)
     cap = bound if bound <= FLAGS_NOSYNC_LIMIT else int(off[-1].item())
@@ -84,10 +91,12 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Tuple[Tensor, Tensor], t2: Optio
     cnt1 = torch.empty(B, dtype=torch.int32, device=dev)
     cnt2 = torch.empty(B, dtype=torch.int32, device=dev) if t2 is not None else None
     status = torch.zeros(1, dtype=torch.int32, device=dev)
+    _mark("cn_prep")
     check(_lib.lib().ocn_cn_flags(ptr(rowptrA), ptr(colA), ptr(t1[0]), ptr(t1[1]),
                                   ptr(t2[0] if t2 else None), ptr(t2[1] if t2 else None),
                                   ptr(src), ptr(dst), B, ptr(off), ptr(flags), cap, ptr(hist),
                                   ptr(cnt1), ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_flags")
+    _mark("cn_flags")
     return off, flags, hist, cnt1, cnt2, status
 
 
@@ -98,6 +107,7 @@ def cn_weights_cn5(hist: Tensor, innerprod: Tensor) -> Tensor:
     scal = torch.zeros(4, dtype=torch.int32, device=hist.device)
     check(_lib.lib().ocn_cn_weights_cn5(ptr(hist), hist.shape[0], ptr(ip), ptr(scal), stream_ptr()),
           "ocn_cn_weights_cn5")
+    _mark("cn_weights")
     return hist.view(torch.float32)
 
 
@@ -105,6 +115,7 @@ def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
     _req(hist, torch.int32, "hist", 2)
     check(_lib.lib().ocn_cn_weights_cn7(ptr(hist), hist.shape[0], float(sum_fill), stream_ptr()),
           "ocn_cn_weights_cn7")
+    _mark("cn_weights")
     return hist.view(torch.float32)
 
 
@@ -118,6 +129,7 @@ def cn_gather(rowptrA, colA, src, dst, off, flags, weights: Tensor, h: Tensor):
     check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), B, ptr(off), ptr(flags),
                                    ptr(weights), ptr(h), H, ptr(out[0]), ptr(out[1]), ptr(out[2]),
                                    stream_ptr()), "ocn_cn_gather")
+    _mark("cn_gather")
     return out[0], out[1], out[2]
 
 
@@ -172,3 +184,32 @@ def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int):
         check(l.ocn_spgemm_pattern_fill(ptr(rowptrA), ptr(colA), n, ptr(rowptrB), ptr(colB), n_cols_b,
                                         ptr(rowptrC), ptr(colC), stream_ptr()), "ocn_spgemm_pattern_fill")
     return rowptrC, colC
+
+
+LN_WIDTHS = (16, 32, 64, 128, 256, 512)
+
+
+def rows_ln_relu(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu: bool, inplace: bool = False) -> Tensor:
+    """LayerNorm over the last dim of a [rows, H] fp32 matrix, optionally followed by ReLU."""
+    _req(x, torch.float32, "x", 2)
+    _req(gamma, torch.float32, "gamma", 1); _req(beta, torch.float32, "beta", 1)
+    rows, H = x.shape
+    if gamma.numel() != H or beta.numel() != H or H not in LN_WIDTHS:
+        raise ValueError("rows_ln_relu: unsupported width")
+    y = x if inplace else torch.empty_like(x)
+    check(_lib.lib().ocn_rows_ln_relu(ptr(x), ptr(gamma), ptr(beta), float(eps), int(relu), rows, H, ptr(y),
+                                      stream_ptr()), "ocn_rows_ln_relu")
+    return y
+
+
+def combine3(coef: Tensor, x1: Tensor, x2: Tensor, x3: Tensor) -> Tensor:
+    """coef[0]*x1 + coef[1]*x2 + coef[2]*x3 with the coefficients read on the device."""
+    _req(coef, torch.float32, "coef", 1)
+    for t, nm in ((x1, "x1"), (x2, "x2"), (x3, "x3")):
+        _req(t, torch.float32, nm)
+    if coef.numel() != 3 or x1.shape != x2.shape or x1.shape != x3.shape or x1.numel() % 4:
+        raise ValueError("combine3: shape mismatch")
+    out = torch.empty_like(x1)
+    check(_lib.lib().ocn_combine3(ptr(coef), ptr(x1), ptr(x2), ptr(x3), x1.numel(), ptr(out), stream_ptr()),
+          "ocn_combine3")
+    return out

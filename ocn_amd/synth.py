@@ -33,40 +33,58 @@ def _powerlaw_weights(n: int, avg_deg: float, max_deg: int, gamma: float, g: tor
 
 
 def chung_lu_graph(n: int, avg_deg: float, max_deg: int, seed: int = 0, gamma: float = 2.3,
-                   clique_frac: float = 0.0) -> Tensor:
-    """Return an undirected edge list [2, m] (each edge once, src < dst)."""
+                   clique_frac: float = 0.0, window: int = 512) -> Tensor:
+    """Return an undirected edge list [2, m] (each edge once, src < dst).
+
+    Endpoints are drawn in proportion to power-law node weights (Chung-Lu).  A ``clique_frac``
+    share of the edges comes from cliques of 3-6 nodes whose members are drawn, again by weight,
+    from a window of +-``window`` ids around a weight-drawn lead: hubs then sit in many
+    overlapping cliques, which gives both the heavy degree tail and the triangles."""
     g = torch.Generator().manual_seed(seed)
     w = _powerlaw_weights(n, avg_deg, max_deg, gamma, g)
     cdf = torch.cumsum(w, 0)
     cdf /= cdf[-1].clone()
+    cdf0 = torch.cat([torch.zeros(1, dtype=cdf.dtype), cdf])       # cdf0[i] = mass of ids < i
     m_target = int(n * avg_deg / 2)
 
     def draw(k: int) -> Tensor:
         return torch.searchsorted(cdf, torch.rand(k, generator=g, dtype=torch.float64)).clamp_(max=n - 1)
 
-    parts = []
-    m_cl = int(m_target * clique_frac)
-    if m_cl > 0:
-        # cliques of size 3..6: a "lead" node drawn by weight, the rest from a window of
-        # nearby ids (locality -> repeated co-occurrence -> triangles)
-        sizes = torch.randint(3, 7, (max(m_cl // 5, 1),), generator=g)
-        lead = draw(sizes.numel())
+    def cliques(m_edges: int) -> Tensor:
         kmax = 6
-        off = torch.randint(-64, 65, (sizes.numel(), kmax), generator=g)
-        mem = (lead[:, None] + off).remainder(n)
+        sizes = torch.randint(3, kmax + 1, (max(m_edges // 7, 1),), generator=g)
+        lead = draw(sizes.numel())
+        lo = (lead - window).clamp_(min=0)
+        hi = (lead + window + 1).clamp_(max=n)
+        u = torch.rand(sizes.numel(), kmax, generator=g, dtype=torch.float64)
+        mass = cdf0[lo][:, None] + u * (cdf0[hi] - cdf0[lo])[:, None]
+        mem = torch.searchsorted(cdf, mass).clamp_(max=n - 1)
         mem[:, 0] = lead
         valid = torch.arange(kmax)[None, :] < sizes[:, None]
         iu, ju = torch.triu_indices(kmax, kmax, offset=1)
-        a, b = mem[:, iu], mem[:, ju]
         ok = valid[:, iu] & valid[:, ju]
-        parts.append(torch.stack([a[ok], b[ok]]))
-    m_rand = int((m_target - (parts[0].shape[1] if parts else 0)) * 1.08) + 8
-    if m_rand > 0:
-        parts.append(torch.stack([draw(m_rand), draw(m_rand)]))
-    ei = torch.cat(parts, dim=1)
-    lo, hi = torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])
-    keep = lo != hi
-    key = torch.unique(lo[keep] * n + hi[keep])
+        return torch.stack([mem[:, iu][ok], mem[:, ju][ok]])
+
+    def dedup(parts) -> Tensor:
+        ei = torch.cat(parts, dim=1)
+        lo, hi = torch.minimum(ei[0], ei[1]), torch.maximum(ei[0], ei[1])
+        keep = lo != hi
+        return torch.unique(lo[keep] * n + hi[keep])
+
+    m_cl = int(m_target * clique_frac)
+    key_cl = torch.zeros(0, dtype=torch.long)
+    for _ in range(8):                       # duplicates inside windows are common: top up
+        if key_cl.numel() >= m_cl:
+            break
+        need = m_cl - key_cl.numel()
+        new = dedup([cliques(int(need * 1.15) + 16)])
+        key_cl = torch.unique(torch.cat([key_cl, new]))
+    key = key_cl
+    for _ in range(8):
+        if key.numel() >= m_target:
+            break
+        need = int((m_target - key.numel()) * 1.05) + 8
+        key = torch.unique(torch.cat([key, dedup([torch.stack([draw(need), draw(need)])])]))
     if key.numel() > m_target:
         key = key[torch.randperm(key.numel(), generator=g)[:m_target]].sort().values
     return torch.stack([torch.div(key, n, rounding_mode="floor"), key % n])

@@ -327,3 +327,22 @@ def test_properties_collab_shape(hiplib):
     k1, k2 = int((hist[:, 0] >= 2).sum()), int((hist[:, 1] >= 1).sum())
     assert abs(o1[:, 0].double().sum().item() - k1) <= 1e-4 * k1 + 1e-3
     assert abs(o2[:, 0].double().sum().item() - k2) <= 1e-4 * k2 + 1e-3
+
+
+# ---- MLP-head glue kernels (floating point: plain torch fp32 reference) ----------------------
+@pytest.mark.parametrize("H", [16, 64, 256, 512])
+def test_rows_ln_relu_and_combine3(hiplib, H):
+    from ocn_amd import ops
+    torch.manual_seed(H)
+    x = (torch.randn(1000, H) * 3 + 0.5).to(DEV)
+    g, b = torch.randn(H, device=DEV), torch.randn(H, device=DEV)
+    for relu in (False, True):
+        ref = torch.nn.functional.layer_norm(x, (H,), g, b, 1e-5)
+        ref = torch.relu(ref) if relu else ref
+        got = ops.rows_ln_relu(x, g, b, 1e-5, relu)
+        assert torch.allclose(got, ref, atol=2e-6, rtol=2e-6), (got - ref).abs().max()
+    y = x.clone()
+    assert ops.rows_ln_relu(y, g, b, 1e-5, True, inplace=True).data_ptr() == y.data_ptr()
+    c = torch.tensor([0.73, 0.41, -1.3], device=DEV)
+    a1, a2, a3 = torch.randn(3, 1000, H, device=DEV)
+    assert torch.equal(ops.combine3(c, a1, a2, a3), c[0] * a1 + c[1] * a2 + c[2] * a3)
