@@ -1,0 +1,83 @@
+"""CPU suite, part 3: the edge-sharding layer (ocn_amd/dist.py) with two gloo ranks.
+
+What must hold for the sharded run to equal the single-device batch: the
+per-column histograms of the shards sum to the global histogram (integer all-reduce), and the
+all-gather puts the scores back in batch order even when the batch does not divide evenly."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ocn_amd.dist import allreduce_hist, gather_scores, shard_bounds
+
+
+def test_shard_bounds_cover_batch_contiguously():
+    for total, world in [(10, 3), (65536, 8), (5, 8), (0, 2), (7, 1)]:
+        b = shard_bounds(total, world)
+        assert len(b) == world and b[0][0] == 0 and b[-1][1] == total
+        assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        sizes = [e - s for s, e in b]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def _hist_of(O, adj, adj2, e, n):
+    cn1, cn2 = O.adjoverlap(adj, adj, e), O.adjoverlap(adj, adj2, e)
+    union = torch.unique(torch.cat([O.spm2elem(cn1), O.spm2elem(cn2)]))
+    h = torch.zeros(n, 4, dtype=torch.int32)
+    h[:, 0] = torch.bincount(cn1.col, minlength=n)
+    h[:, 1] = torch.bincount(cn2.col, minlength=n)
+    h[:, 2] = torch.bincount(union & 0xFFFFFFFF, minlength=n)
+    return h
+
+
+def _worker(rank, world, port, B, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import ocn_oracle as O
+        from ocn_amd.synth import chung_lu_graph, sample_edges
+        n = 300
+        ei = chung_lu_graph(n, 8, 60, seed=5, clique_frac=0.5)
+        adj = O.to_symmetric(O.from_edge_index(ei, n))
+        adj2 = O.adj2_sparse(adj)
+        edges = sample_edges(adj.row, adj.col, n, B, seed=6)           # same global batch on every rank
+        s, e = shard_bounds(B, world)[rank]
+        local = _hist_of(O, adj, adj2, edges[:, s:e], n)
+        glob = allreduce_hist(local.clone())
+        ok_hist = torch.equal(glob, _hist_of(O, adj, adj2, edges, n))
+        # scores: any per-edge function of the global edge id; gather must restore batch order
+        mine = (torch.arange(s, e, dtype=torch.float32) * 0.5 + 1).reshape(-1, 1)
+        allsc = gather_scores(mine, B)
+        ok_gather = torch.equal(allsc, (torch.arange(B, dtype=torch.float32) * 0.5 + 1).reshape(-1, 1))
+        out.put((rank, ok_hist, ok_gather, tuple(allsc.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B", [64, 77])
+def test_two_rank_histogram_allreduce_and_score_gather(B):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok_hist, ok_gather, shape in res:
+        assert ok_hist, f"rank {rank}: summed shard histograms differ from the global batch"
+        assert ok_gather and shape == (B, 1)
+
+
+def test_single_process_helpers_are_identity():
+    h = torch.ones(5, 4, dtype=torch.int32)
+    assert allreduce_hist(h) is h
+    x = torch.randn(6, 1)
+    assert gather_scores(x, 6) is x
