@@ -50,37 +50,52 @@ int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, vo
  * of a batch fused.  For edge e=(i,j) and the p-th neighbour k of i in A:
  *   flags[off[e]+p] = [k in T1 row j] | [k in T2 row j] << 1
  * cnt1[e] / cnt2[e] = |cn1_e| / |cn2_e| (the integer CN counts), and the per-column
- * histograms hist[k] = {n1, n2, n_union, 0} are accumulated (cn.sum(dim=0), model.py:2261,
- * 3114; must be zero on entry).  T2 may be NULL (single adjoverlap call).
+ * histograms are accumulated (cn.sum(dim=0), model.py:2261,3114): hist[k] = {packed, walks}
+ * with packed = n1 | n2 << 21 | n_union << 42 (one 64-bit atomic per CN entry) and walks = 0
+ * here; must be zero on entry; B < 2^21.  T2 may be NULL (single adjoverlap call).
  * status: device int32, bit 0 set if off[B] > flags_cap (nothing is written past the cap). */
 int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA,
                  const int64_t* rowptrT1, const int32_t* colT1,
                  const int64_t* rowptrT2, const int32_t* colT2,
                  const int64_t* src, const int64_t* dst, int64_t B,
                  const int64_t* off, uint8_t* flags, int64_t flags_cap,
-                 int32_t* hist /* [N][4] */, int32_t* cnt1, int32_t* cnt2,
+                 uint64_t* hist /* [N][2] */, int32_t* cnt1, int32_t* cnt2,
                  int32_t* status, void* stream);
 
-/* Per-column weights, written IN PLACE over hist (int32[N][4] -> float[N][4]) as
- *   {w1, w2_both, w2_only2, w2_only1}:
+/* The pygho route get_cn1_cn2 (NeighborOverlap_large_ppa.py:147-173, NeighborOverlapCitation2.py:
+ * 78-104) without forming Ej·A: cn1 = N(i) ∩ N(j) as above; cn2[e,k] = |N(k) ∩ N(j)| (number of
+ * 2-walks j -> k) for k in N(i), kept where > 0.  wc[off[e]+p] receives the walk count, hist[k]
+ * additionally accumulates walks = sum of the counts of column k; cnt2[e] = number of non-zero
+ * entries of cn2 row e. */
+int ocn_cn_walk_flags(const int64_t* rowptrA, const int32_t* colA,
+                      const int64_t* src, const int64_t* dst, int64_t B,
+                      const int64_t* off, uint8_t* flags, int32_t* wc, int64_t flags_cap,
+                      uint64_t* hist /* [N][2] */, int32_t* cnt1, int32_t* cnt2,
+                      int32_t* status, void* stream);
+
+/* Per-column weights, written IN PLACE over hist (uint64[N][2] -> float[N][4]) as
+ *   {w1, t, inv2, 0}: a cn1 entry pools with w1; a union entry whose cn2 value is c (1.0 for the
+ *   pattern route, the walk count for the valued route) pools into xcn2 with
+ *   (c*[in cn2] - t*[in cn1]) * inv2.
  * cn5 (model.py:2261-2272, 2352-2413): w1 = 1/S1 (0 if S1 < 2); scale = max w1 over cn1
- * entries; nip = innerprod/scale (scale>0); v = cn2 - nip*ncn1 on the union pattern;
- * S2 = column sums of v (0 -> 1); w2_* = v_* / S2.  `innerprod` is a device float[1] (the
- * module buffer); `scalars` is a device scratch of 4 int32, zero on entry.
+ * entries; nip = innerprod/scale (scale>0); t = nip*w1; S2 = column sums of cn2 - nip*ncn1 over
+ * the union pattern (0 -> 1); inv2 = 1/S2.  `innerprod` is a device float[1] (the module buffer);
+ * `scalars` is a device scratch of 4 int32, zero on entry; `valued` != 0 for walk-count cn2.
  * cn7 (model.py:3114-3126, 3186-3209): w1 = 1/S1, `sum_fill` where S1 < 2; cn2 raw ->
- * {w1, 1, 1, 0}. */
-int ocn_cn_weights_cn5(int32_t* hist, int64_t N, const float* innerprod, int32_t* scalars,
-                       void* stream);
-int ocn_cn_weights_cn7(int32_t* hist, int64_t N, float sum_fill, void* stream);
+ * {w1, 0, 1, 0}. */
+int ocn_cn_weights_cn5(uint64_t* hist, int64_t N, const float* innerprod, int32_t* scalars,
+                       int32_t valued, void* stream);
+int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream);
 
 /* The pooling: spmm_add(ncn1, x), spmm_add(ncn2, x) and x[i]*x[j] (model.py:2426-2429,
  * 3213-3216) in one pass.  xcn1[e] = sum_{k in cn1_e} w1[k] h[k]; xcn2[e] = sum over the
- * union pattern of w2_type[k] h[k]; xij[e] = h[i] (.) h[j]; entries in ascending column
- * order, fp32 multiply then add.  h is [N][H] row-major fp32; outputs [B][H]. */
+ * union pattern as above; xij[e] = h[i] (.) h[j]; entries in ascending column order, fp32
+ * multiply then add.  wc = per-neighbour cn2 values of the walk route or NULL (all 1.0).
+ * h is [N][H] row-major fp32; outputs [B][H]. */
 int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA,
                   const int64_t* src, const int64_t* dst, int64_t B,
-                  const int64_t* off, const uint8_t* flags, const float* weights /* [N][4] */,
-                  const float* h, int32_t H,
+                  const int64_t* off, const uint8_t* flags, const int32_t* wc,
+                  const float* weights /* [N][4] */, const float* h, int32_t H,
                   float* xcn1, float* xcn2, float* xij, void* stream);
 
 /* CSR SpMM of the encoders: torch_sparse spmm_add/mean/max (model.py:42-55), PyG GCNConv

@@ -6,14 +6,15 @@ non-zero status, this raises.  ``build()`` compiles it in-tree with hipcc for gf
 from __future__ import annotations
 
 import ctypes
+import glob
 import os
 import subprocess
 from ctypes import c_float, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libocn_hip.so")
-SRC = os.path.join(_HERE, "csrc", "ocn_kernels.hip")
+LIB_PATH = os.environ.get("OCN_LIB_PATH", os.path.join(_HERE, "libocn_hip.so"))
+CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(_ROOT, "include")
 
 # name -> (restype, argtypes); must list every symbol include/ocn_hip.h declares
@@ -24,9 +25,10 @@ SIGNATURES = {
     "ocn_edge_offsets": (c_int32, [_P, _P, c_int64, _P, _P, _P]),
     "ocn_scan_i32": (c_int32, [_P, c_int64, _P, _P, _P]),
     "ocn_cn_flags": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P]),
-    "ocn_cn_weights_cn5": (c_int32, [_P, c_int64, _P, _P, _P]),
+    "ocn_cn_walk_flags": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
+    "ocn_cn_weights_cn5": (c_int32, [_P, c_int64, _P, _P, c_int32, _P]),
     "ocn_cn_weights_cn7": (c_int32, [_P, c_int64, c_float, _P]),
-    "ocn_cn_gather": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int32, _P, _P, _P, _P]),
+    "ocn_cn_gather": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P]),
     "ocn_spmm_csr": (c_int32, [_P, _P, c_int64, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "ocn_deg_rsqrt": (c_int32, [_P, c_int64, c_float, _P, _P]),
     "ocn_spgemm_max_cols": (c_int64, []),
@@ -41,23 +43,28 @@ class OcnHipError(RuntimeError):
     pass
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/ocn_kernels.hip -> ocn_amd/libocn_hip.so for gfx950 (hipcc cross-compiles
-    without a GPU)."""
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
-            os.path.getmtime(SRC), os.path.getmtime(os.path.join(INCLUDE, "ocn_hip.h")),
-            os.path.getmtime(os.path.abspath(__file__))):
-        return LIB_PATH
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
+    """Compile csrc/*.hip -> ocn_amd/libocn_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = out or LIB_PATH
+    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "ocn_hip.h"),
+                        os.path.abspath(__file__)]
+    if not force and not extra_flags and os.path.exists(out) and \
+            os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
            # the reference's CPU kernels round the product and the sum separately; HIP's __fmul_rn /
            # __fadd_rn are plain * and + and would be contracted into FMAs under the default mode
            "-ffp-contract=off",
-           f"-I{INCLUDE}", "-o", LIB_PATH, SRC]
+           f"-I{INCLUDE}", f"-I{CSRC}", *extra_flags, "-o", out, *sources()]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return out
 
 
 _lib = None

@@ -1,0 +1,500 @@
+// The common-neighbour stage: intersection (K1, pattern and walk-count forms), per-column weights
+// (K2) and embedding pooling (K3).  See include/ocn_hip.h for the reference call sites.
+#include "common.h"
+
+typedef unsigned long long u64;
+
+// hist[c] = {packed, walks}: packed = n1 | n2 << 21 | n_union << 42 (one 64-bit atomic per CN entry
+// instead of three 32-bit ones), walks = sum of the walk counts of column c (valued cn2 only).
+#define HF_BITS 21
+#define HF_MASK ((1ull << HF_BITS) - 1ull)
+__device__ __forceinline__ int hf_n1(u64 w) { return (int)(w & HF_MASK); }
+__device__ __forceinline__ int hf_n2(u64 w) { return (int)((w >> HF_BITS) & HF_MASK); }
+__device__ __forceinline__ int hf_nu(u64 w) { return (int)((w >> (2 * HF_BITS)) & HF_MASK); }
+
+// ---------------------------------------------------------------------------------------------
+// sorted-list membership
+// ---------------------------------------------------------------------------------------------
+// Branch-uniform binary search over a[0..n) (global or LDS): every lane of a wave searches the same
+// row, so the trip count is wave-uniform and the top levels of the tree are shared cache lines.
+template <typename P>
+__device__ __forceinline__ bool sorted_has(P a, i64 n, int32_t key) {
+  i64 lo = 0, hi = n;
+  bool found = false;
+  while (lo < hi) {
+    const i64 mid = (lo + hi) >> 1;
+    const int32_t v = a[mid];
+    found |= (v == key);
+    if (v < key) lo = mid + 1; else hi = mid;
+  }
+  return found;
+}
+
+// Two-level search of a long row: `samp` (LDS) holds the row's elements at positions (s*n)>>6,
+// s = 0..63; six LDS probes pick the segment, the remaining log2(n/64) probes go to memory.
+__device__ __forceinline__ bool sampled_has(const int32_t* samp, const int32_t* __restrict__ row, i64 n,
+                                            int32_t key) {
+  int lo = 0, hi = OCN_WAVE;                 // upper bound: lo = number of samples <= key
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (samp[mid] <= key) lo = mid + 1; else hi = mid;
+  }
+  if (lo == 0) return false;
+  const int s = lo - 1;
+  const i64 p0 = ((i64)s * n) >> 6, p1 = ((i64)(s + 1) * n) >> 6;
+  return sorted_has(row + p0, p1 - p0, key);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 (pattern): flags for N(src) against the rows of dst in T1 (and T2)
+// ---------------------------------------------------------------------------------------------
+#define T1_CAP 256
+
+template <bool HAS_T2>
+__global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ rowptrT1, const int32_t* __restrict__ colT1,
+    const i64* __restrict__ rowptrT2, const int32_t* __restrict__ colT2,
+    const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
+    const i64* __restrict__ off, uint8_t* __restrict__ flags, i64 cap,
+    u64* __restrict__ hist, int32_t* __restrict__ cnt1, int32_t* __restrict__ cnt2,
+    int32_t* __restrict__ status) {
+  __shared__ int32_t s_t1[OCN_WPB][T1_CAP];
+  __shared__ int32_t s_t2[OCN_WPB][OCN_WAVE];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && off[B] > cap) atomicOr(status, 1);
+  for (i64 e0 = (i64)blockIdx.x * OCN_WPB; e0 < B; e0 += (i64)gridDim.x * OCN_WPB) {
+    const i64 e = e0 + w;
+    const bool act = e < B;
+    i64 a0 = 0, da = 0, b0 = 0, db = 0, c0 = 0, dc = 0, base = 0;
+    if (act) {
+      const i64 i = src[e], j = dst[e];
+      a0 = rowptrA[i]; da = rowptrA[i + 1] - a0;
+      b0 = rowptrT1[j]; db = rowptrT1[j + 1] - b0;
+      if (HAS_T2) { c0 = rowptrT2[j]; dc = rowptrT2[j + 1] - c0; }
+      base = off[e];
+    }
+    // stage the short target row, and a 64-point sample of the long one, in this wave's LDS slice
+    const bool t1_lds = db <= T1_CAP;
+    if (t1_lds)
+      for (i64 q = lane; q < db; q += OCN_WAVE) s_t1[w][q] = colT1[b0 + q];
+    if (HAS_T2) {
+      if (dc > OCN_WAVE) s_t2[w][lane] = colT2[c0 + (((i64)lane * dc) >> 6)];
+      else if (lane < dc) s_t2[w][lane] = colT2[c0 + lane];
+    }
+    __syncthreads();
+    const bool fits = base + da <= cap;
+    int c1 = 0, c2 = 0;
+    for (i64 p = lane; p < da; p += OCN_WAVE) {
+      const int32_t k = colA[a0 + p];
+      const bool f1 = t1_lds ? sorted_has(&s_t1[w][0], db, k) : sorted_has(colT1 + b0, db, k);
+      bool f2 = false;
+      if (HAS_T2)
+        f2 = dc > OCN_WAVE ? sampled_has(&s_t2[w][0], colT2 + c0, dc, k) : sorted_has(&s_t2[w][0], dc, k);
+      if (fits) flags[base + p] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
+      if (f1 | f2)
+        atomicAdd(hist + 2 * (i64)k, (u64)f1 | ((u64)f2 << HF_BITS) | (1ull << (2 * HF_BITS)));
+      c1 += f1;
+      c2 += f2;
+    }
+    c1 = wave_sum(c1);
+    c2 = wave_sum(c2);
+    if (act && lane == 0) {
+      cnt1[e] = c1;
+      if (cnt2) cnt2[e] = c2;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 (walk counts): the pygho route of NeighborOverlap_large_ppa.py:147-173 without A².
+// cn1 = N(i) ∩ N(j); cn2[e,k] = |N(k) ∩ N(j)| for k in N(i) (number of 2-walks j -> k), kept if > 0.
+// ---------------------------------------------------------------------------------------------
+#define WALK_CAP 1024
+
+__global__ __launch_bounds__(OCN_BLOCK) void cn_walk_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
+    const i64* __restrict__ off, uint8_t* __restrict__ flags, int32_t* __restrict__ wc, i64 cap,
+    u64* __restrict__ hist, int32_t* __restrict__ cnt1, int32_t* __restrict__ cnt2,
+    int32_t* __restrict__ status) {
+  __shared__ int32_t s_nj[OCN_WPB][WALK_CAP];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && off[B] > cap) atomicOr(status, 1);
+  for (i64 e0 = (i64)blockIdx.x * OCN_WPB; e0 < B; e0 += (i64)gridDim.x * OCN_WPB) {
+    const i64 e = e0 + w;
+    const bool act = e < B;
+    i64 a0 = 0, da = 0, b0 = 0, db = 0, base = 0;
+    if (act) {
+      const i64 i = src[e], j = dst[e];
+      a0 = rowptrA[i]; da = rowptrA[i + 1] - a0;
+      b0 = rowptrA[j]; db = rowptrA[j + 1] - b0;
+      base = off[e];
+    }
+    const bool nj_lds = db <= WALK_CAP;
+    if (nj_lds)
+      for (i64 q = lane; q < db; q += OCN_WAVE) s_nj[w][q] = colA[b0 + q];
+    __syncthreads();
+    const bool fits = base + da <= cap;
+    const int32_t* nj_g = colA + b0;
+    int c1 = 0, c2 = 0;
+    for (i64 p = lane; p < da; p += OCN_WAVE) {
+      const int32_t k = colA[a0 + p];
+      const bool f1 = nj_lds ? sorted_has(&s_nj[w][0], db, k) : sorted_has(nj_g, db, k);
+      const i64 k0 = rowptrA[k], dk = rowptrA[k + 1] - k0;
+      int walks = 0;
+      if (dk <= db || !nj_lds) {
+        // walk N(k), look each member up in N(j)
+        for (i64 q = 0; q < dk; ++q) {
+          const int32_t m = colA[k0 + q];
+          walks += nj_lds ? sorted_has(&s_nj[w][0], db, m) : sorted_has(nj_g, db, m);
+        }
+      } else {
+        // N(j) is the shorter list and sits in LDS: look its members up in N(k)
+        for (i64 q = 0; q < db; ++q) walks += sorted_has(colA + k0, dk, s_nj[w][q]);
+      }
+      const bool f2 = walks > 0;
+      if (fits) {
+        flags[base + p] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
+        wc[base + p] = walks;
+      }
+      if (f1 | f2) {
+        atomicAdd(hist + 2 * (i64)k, (u64)f1 | ((u64)f2 << HF_BITS) | (1ull << (2 * HF_BITS)));
+        if (f2) atomicAdd(hist + 2 * (i64)k + 1, (u64)walks);
+      }
+      c1 += f1;
+      c2 += f2;
+    }
+    c1 = wave_sum(c1);
+    c2 = wave_sum(c2);
+    if (act && lane == 0) {
+      cnt1[e] = c1;
+      cnt2[e] = c2;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: per-column weights {w1, t, inv2, 0}, in place over the histogram
+//   pooled xcn1 uses w1;  a union entry with cn2 value c (1, or the walk count) contributes
+//   (c·[in cn2] − t·[in cn1]) · inv2 to xcn2.
+// ---------------------------------------------------------------------------------------------
+// scalars[0] (zero on entry) ends as: 0 = no union entry at all; -1 = union entries but no column
+// with n1 >= 2; otherwise min{n1 : n1 >= 2} - INT_MAX - 1 (<= -2).  One atomicMin per workgroup,
+// skipped when the word already holds something at least as small.
+__global__ __launch_bounds__(OCN_BLOCK) void cn5_column_stats(const u64* __restrict__ hist, i64 N,
+                                                              int32_t* __restrict__ scalars) {
+  __shared__ int sh[OCN_WPB];
+  int v = 0;
+  for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (i64)gridDim.x * blockDim.x) {
+    const u64 pk = hist[2 * c];
+    int t = pk ? -1 : 0;
+    const int n1 = hf_n1(pk);
+    if (n1 >= 2) t = n1 - 0x7fffffff - 1;
+    v = t < v ? t : v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int t = __shfl_xor(v, o, OCN_WAVE);
+    v = t < v ? t : v;
+  }
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < OCN_WPB; ++i) v = sh[i] < v ? sh[i] : v;
+    if (v < 0 && v < __hip_atomic_load(scalars, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      atomicMin(scalars, v);
+  }
+}
+
+__global__ __launch_bounds__(OCN_BLOCK) void cn5_column_weights(u64* __restrict__ hist, i64 N,
+                                                                const float* __restrict__ innerprod,
+                                                                const int32_t* __restrict__ scalars,
+                                                                int valued) {
+  // model.py:2370-2376: scale = max |ncn1| over the union-aligned vector (1.0 if it is empty)
+  const int sc = scalars[0];
+  float scale;
+  if (sc == 0) scale = 1.0f;                                        // empty union vector
+  else if (sc == -1) scale = 0.0f;                                  // only singleton columns: every ncn1 value is 0
+  else scale = 1.0f / (float)(sc + 0x7fffffff + 1);                 // largest 1/S1 among columns with S1 >= 2
+  const float ip = innerprod[0];
+  const float nip = scale > 0.0f ? ip / scale : ip;
+  float4* wout = reinterpret_cast<float4*>(hist);
+  for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (i64)gridDim.x * blockDim.x) {
+    const u64 pk = hist[2 * c];
+    if (pk == 0) continue;                               // untouched column: never read by the gather
+    const u64 walks = hist[2 * c + 1];
+    const int n1 = hf_n1(pk), n2 = hf_n2(pk), nb = n1 + n2 - hf_nu(pk);
+    const float inv1 = n1 >= 2 ? 1.0f / (float)n1 : 0.0f;              // :2263-2266 (Q2)
+    const float t = __fmul_rn(nip, inv1);                              // nip * ncn1 value
+    // :2405-2406 column sum of v = cn2 − nip·ncn1 over the union pattern.  The reference adds the
+    // entries one by one in fp32 (edge order); here the distinct values are combined by their
+    // integer multiplicities in fp64 and rounded once.  Exact whenever nip == 0 (S2 = colsum(cn2)).
+    double s2d;
+    if (!valued) {
+      const float v_both = __fsub_rn(1.0f, t);                         // :2380-2384
+      const float v_only2 = __fsub_rn(1.0f, __fmul_rn(nip, 0.0f));
+      const float v_only1 = __fsub_rn(0.0f, t);
+      s2d = (double)(n2 - nb) * (double)v_only2 + (double)nb * (double)v_both +
+            (double)(n1 - nb) * (double)v_only1;
+    } else {
+      s2d = (double)walks - (double)n1 * (double)t;
+    }
+    float S2 = (float)s2d;
+    if (S2 == 0.0f) S2 = 1.0f;                                         // :2409
+    wout[c] = make_float4(inv1, t, 1.0f / S2, 0.0f);                   // :2410-2413
+  }
+}
+
+__global__ __launch_bounds__(OCN_BLOCK) void cn7_column_weights(u64* __restrict__ hist, i64 N,
+                                                                float sum_fill) {
+  float4* wout = reinterpret_cast<float4*>(hist);
+  for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (i64)gridDim.x * blockDim.x) {
+    const u64 pk = hist[2 * c];
+    if (pk == 0) continue;
+    const int n1 = hf_n1(pk);
+    const float inv1 = n1 >= 2 ? 1.0f / (float)n1 : sum_fill;          // model.py:3116-3120
+    // x T0 == 1 (model.py:2958, 3141-3165); cn2 raw (Q5, :3186-3209): t = 0, inv2 = 1
+    wout[c] = make_float4(__fmul_rn(inv1, 1.0f), 0.0f, 1.0f, 0.0f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: pooling — gather embedding rows over the flagged neighbours
+// ---------------------------------------------------------------------------------------------
+// per-entry weights from the flag byte, the column's {w1, t, inv2} and the cn2 value c
+__device__ __forceinline__ void entry_weights(unsigned f, const float4& w, float c, float& wa, float& wb) {
+  wa = (f & OCN_F_CN1) ? w.x : 0.f;
+  const float v = __fsub_rn((f & OCN_F_CN2) ? c : 0.f, (f & OCN_F_CN1) ? w.y : 0.f);
+  wb = __fmul_rn(v, w.z);
+}
+
+// LPE lanes cooperate on one edge; each lane owns NV float4 of the H = LPE*NV*4 features.
+template <int LPE, int NV>
+__global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
+    const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
+    const float4* __restrict__ weights, const float* __restrict__ h, int H,
+    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
+  constexpr int GPW = OCN_WAVE / LPE;
+  constexpr int UNR = 4;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane % LPE;
+  const int gbase = lane - gl;
+  const i64 e = ((i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
+  if (e >= B) return;                       // whole group leaves together
+  const i64 i = src[e], j = dst[e];
+  const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+  const i64 base = off[e];
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  const i64 rowq = H >> 2;                  // float4 per row
+
+  float4 acc1[NV], acc2[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (i64 p0 = 0; p0 < da; p0 += LPE) {
+    const i64 p = p0 + gl;
+    int32_t k = 0;
+    unsigned f = 0;
+    if (p < da) { k = colA[a0 + p]; f = flags[base + p]; }
+    float wa = 0.f, wb = 0.f;
+    if (f) entry_weights(f, weights[k], wc ? (float)wc[base + p] : 1.0f, wa, wb);
+    const bool need = (wa != 0.f) | (wb != 0.f);
+    unsigned long long m = __ballot(need);
+    if (LPE < 64) m = (m >> gbase) & ((1ull << (LPE & 63)) - 1ull);
+    while (m) {
+      int bsel[UNR];
+#pragma unroll
+      for (int t = 0; t < UNR; ++t) {
+        bsel[t] = m ? (__ffsll((long long)m) - 1) : -1;
+        m &= m - 1;                          // no-op once m == 0
+      }
+      int32_t kk[UNR];
+      float wwa[UNR], wwb[UNR];
+      float4 x[UNR][NV];
+#pragma unroll
+      for (int t = 0; t < UNR; ++t) {
+        const int sl = gbase + (bsel[t] < 0 ? 0 : bsel[t]);
+        kk[t] = __shfl(k, sl, OCN_WAVE);
+        wwa[t] = __shfl(wa, sl, OCN_WAVE);
+        wwb[t] = __shfl(wb, sl, OCN_WAVE);
+        if (bsel[t] >= 0) {
+          const float4* row = h4 + (i64)kk[t] * rowq + gl;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) x[t][v] = row[v * LPE];
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < UNR; ++t) {
+        if (bsel[t] >= 0) {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            axpy4(acc1[v], wwa[t], x[t][v]);
+            axpy4(acc2[v], wwb[t], x[t][v]);
+          }
+        }
+      }
+    }
+  }
+  const float4* hi = h4 + i * rowq + gl;
+  const float4* hj = h4 + j * rowq + gl;
+  float4* o1 = reinterpret_cast<float4*>(xcn1) + e * rowq + gl;
+  float4* o2 = reinterpret_cast<float4*>(xcn2) + e * rowq + gl;
+  float4* o3 = reinterpret_cast<float4*>(xij) + e * rowq + gl;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const float4 a = hi[v * LPE], b = hj[v * LPE];
+    o1[v * LPE] = acc1[v];
+    o2[v * LPE] = acc2[v];
+    o3[v * LPE] = make_float4(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y), __fmul_rn(a.z, b.z),
+                              __fmul_rn(a.w, b.w));
+  }
+}
+
+// any H: one wave per edge, one feature per lane per 64-wide chunk (re-walks the flags per chunk)
+__global__ __launch_bounds__(OCN_BLOCK) void cn_gather_generic(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
+    const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
+    const float4* __restrict__ weights, const float* __restrict__ h, int H,
+    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
+  const int lane = threadIdx.x & 63;
+  const i64 e = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6);
+  if (e >= B) return;
+  const i64 i = src[e], j = dst[e];
+  const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+  const i64 base = off[e];
+  for (int f0 = 0; f0 < H; f0 += OCN_WAVE) {
+    const int ft = f0 + lane;
+    const bool fin = ft < H;
+    float acc1 = 0.f, acc2 = 0.f;
+    for (i64 p0 = 0; p0 < da; p0 += OCN_WAVE) {
+      const i64 p = p0 + lane;
+      int32_t k = 0;
+      unsigned f = 0;
+      if (p < da) { k = colA[a0 + p]; f = flags[base + p]; }
+      float wa = 0.f, wb = 0.f;
+      if (f) entry_weights(f, weights[k], wc ? (float)wc[base + p] : 1.0f, wa, wb);
+      unsigned long long m = __ballot((wa != 0.f) | (wb != 0.f));
+      while (m) {
+        const int b = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int32_t kk = __shfl(k, b, OCN_WAVE);
+        const float a = __shfl(wa, b, OCN_WAVE), bb = __shfl(wb, b, OCN_WAVE);
+        if (fin) {
+          const float x = h[(i64)kk * H + ft];
+          acc1 = __fadd_rn(acc1, __fmul_rn(a, x));
+          acc2 = __fadd_rn(acc2, __fmul_rn(bb, x));
+        }
+      }
+    }
+    if (fin) {
+      xcn1[e * H + ft] = acc1;
+      xcn2[e * H + ft] = acc2;
+      xij[e * H + ft] = __fmul_rn(h[i * H + ft], h[j * H + ft]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* rowptrT1,
+                 const int32_t* colT1, const int64_t* rowptrT2, const int32_t* colT2,
+                 const int64_t* src, const int64_t* dst, int64_t B, const int64_t* off,
+                 uint8_t* flags, int64_t flags_cap, uint64_t* hist, int32_t* cnt1, int32_t* cnt2,
+                 int32_t* status, void* stream) {
+  if (B < 0 || flags_cap < 0 || B > (int64_t)HF_MASK) return OCN_EINVAL;
+  if (B == 0) return 0;
+  if (!rowptrA || !rowptrT1 || !src || !dst || !off || !hist || !cnt1 || !status) return OCN_EINVAL;
+  // col pointers may legitimately be NULL for an adjacency with no entries
+  const int grid = grid_for((B + OCN_WPB - 1) / OCN_WPB);
+  hipStream_t st = (hipStream_t)stream;
+  if (rowptrT2)
+    hipLaunchKernelGGL(cn_flags_kernel<true>, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
+                       colA, (const i64*)rowptrT1, colT1, (const i64*)rowptrT2, colT2, (const i64*)src,
+                       (const i64*)dst, (i64)B, (const i64*)off, flags, (i64)flags_cap, (u64*)hist, cnt1,
+                       cnt2, status);
+  else
+    hipLaunchKernelGGL(cn_flags_kernel<false>, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
+                       colA, (const i64*)rowptrT1, colT1, (const i64*)nullptr, (const int32_t*)nullptr,
+                       (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, (i64)flags_cap,
+                       (u64*)hist, cnt1, cnt2, status);
+  return launch_status();
+}
+
+int ocn_cn_walk_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
+                      const int64_t* dst, int64_t B, const int64_t* off, uint8_t* flags, int32_t* wc,
+                      int64_t flags_cap, uint64_t* hist, int32_t* cnt1, int32_t* cnt2, int32_t* status,
+                      void* stream) {
+  if (B < 0 || flags_cap < 0 || B > (int64_t)HF_MASK) return OCN_EINVAL;
+  if (B == 0) return 0;
+  if (!rowptrA || !src || !dst || !off || !hist || !cnt1 || !cnt2 || !status) return OCN_EINVAL;
+  if (flags_cap > 0 && (!flags || !wc)) return OCN_EINVAL;
+  const int grid = grid_for((B + OCN_WPB - 1) / OCN_WPB);
+  hipLaunchKernelGGL(cn_walk_kernel, dim3(grid), dim3(OCN_BLOCK), 0, (hipStream_t)stream,
+                     (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off,
+                     flags, wc, (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
+  return launch_status();
+}
+
+int ocn_cn_weights_cn5(uint64_t* hist, int64_t N, const float* innerprod, int32_t* scalars,
+                       int32_t valued, void* stream) {
+  if (N < 0 || (N > 0 && (!hist || !innerprod || !scalars))) return OCN_EINVAL;
+  if (N == 0) return 0;
+  const int grid = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cn5_column_stats, dim3(grid < 512 ? grid : 512), dim3(OCN_BLOCK), 0, st,
+                     (const u64*)hist, (i64)N, scalars);
+  hipLaunchKernelGGL(cn5_column_weights, dim3(grid), dim3(OCN_BLOCK), 0, st, (u64*)hist, (i64)N,
+                     innerprod, (const int32_t*)scalars, (int)valued);
+  return launch_status();
+}
+
+int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream) {
+  if (N < 0 || (N > 0 && !hist)) return OCN_EINVAL;
+  if (N == 0) return 0;
+  const int grid = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
+  hipLaunchKernelGGL(cn7_column_weights, dim3(grid), dim3(OCN_BLOCK), 0, (hipStream_t)stream,
+                     (u64*)hist, (i64)N, sum_fill);
+  return launch_status();
+}
+
+#define GATHER_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, \
+                    flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij
+#define LAUNCH_GATHER(LPE, NV)                                                                      \
+  do {                                                                                              \
+    const i64 epb = (i64)OCN_WPB * (OCN_WAVE / (LPE));                                              \
+    hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)),          \
+                       dim3(OCN_BLOCK), 0, st, GATHER_ARGS);                                        \
+  } while (0)
+
+int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
+                  const int64_t* dst, int64_t B, const int64_t* off, const uint8_t* flags,
+                  const int32_t* wc, const float* weights, const float* h, int32_t H, float* xcn1,
+                  float* xcn2, float* xij, void* stream) {
+  if (B < 0 || H <= 0) return OCN_EINVAL;
+  if (B == 0) return 0;
+  if (!rowptrA || !src || !dst || !off || !weights || !h || !xcn1 || !xcn2 || !xij) return OCN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  switch (H) {
+    case 16:  LAUNCH_GATHER(4, 1); break;
+    case 32:  LAUNCH_GATHER(8, 1); break;
+    case 64:  LAUNCH_GATHER(16, 1); break;
+    case 128: LAUNCH_GATHER(32, 1); break;
+    case 256: LAUNCH_GATHER(64, 1); break;
+    case 512: LAUNCH_GATHER(64, 2); break;
+    default:
+      hipLaunchKernelGGL(cn_gather_generic, dim3((unsigned)((B + OCN_WPB - 1) / OCN_WPB)),
+                         dim3(OCN_BLOCK), 0, st, GATHER_ARGS);
+  }
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// Shared primitives of the libocn_hip.so translation units (gfx950, wave64, 256-thread workgroups).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ocn_hip.h"
+
+#define OCN_WAVE 64
+#define OCN_BLOCK 256
+#define OCN_WPB (OCN_BLOCK / OCN_WAVE)
+
+typedef long long i64;
+
+static inline int launch_status() { return (int)hipGetLastError(); }
+
+static inline int grid_for(i64 items_per_block_units, i64 cap = (1 << 20)) {
+  i64 g = items_per_block_units < 1 ? 1 : items_per_block_units;
+  return (int)(g > cap ? cap : g);
+}
+
+// ---------------------------------------------------------------------------------------------
+// wave / block primitives
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, OCN_WAVE);
+  return v;
+}
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ i64 wave_incl_scan(i64 v, int lane) {
+#pragma unroll
+  for (int o = 1; o < OCN_WAVE; o <<= 1) {
+    i64 t = __shfl_up(v, o, OCN_WAVE);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns the thread's prefix and
+// the block total.  `sh` is 2*OCN_WPB i64 of LDS.
+__device__ __forceinline__ i64 block_excl_scan(i64 v, i64* sh, i64* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  i64 inc = wave_incl_scan(v, lane);
+  if (lane == 63) sh[w] = inc;
+  __syncthreads();
+  i64 base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < OCN_WPB; ++i) {
+    i64 s = sh[i];
+    if (i < w) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__device__ __forceinline__ void axpy4(float4& acc, float w, const float4& x) {
+  acc.x = __fadd_rn(acc.x, __fmul_rn(w, x.x));
+  acc.y = __fadd_rn(acc.y, __fmul_rn(w, x.y));
+  acc.z = __fadd_rn(acc.z, __fmul_rn(w, x.z));
+  acc.w = __fadd_rn(acc.w, __fmul_rn(w, x.w));
+}
+

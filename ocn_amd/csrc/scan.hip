@@ -1,0 +1,117 @@
+// Exclusive scans: batch-row offsets (deg of src per edge) and int32 counts -> int64 offsets.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+// scans (edge offsets, row offsets)
+// ---------------------------------------------------------------------------------------------
+#define SCAN_IPT 8
+#define SCAN_TILE (OCN_BLOCK * SCAN_IPT)
+
+struct DegOfSrc {
+  const i64* rowptr;
+  const i64* src;
+  __device__ __forceinline__ i64 operator()(i64 e) const {
+    i64 i = src[e];
+    return rowptr[i + 1] - rowptr[i];
+  }
+};
+struct I32In {
+  const int32_t* in;
+  __device__ __forceinline__ i64 operator()(i64 e) const { return (i64)in[e]; }
+};
+
+template <typename Op>
+__global__ __launch_bounds__(OCN_BLOCK) void scan_tile_sums(Op op, i64 n, i64* tile_sum) {
+  __shared__ i64 sh[OCN_WPB];
+  const i64 base = (i64)blockIdx.x * SCAN_TILE;
+  i64 s = 0;
+#pragma unroll
+  for (int t = 0; t < SCAN_IPT; ++t) {
+    i64 e = base + (i64)t * OCN_BLOCK + threadIdx.x;
+    if (e < n) s += op(e);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    i64 t = 0;
+    for (int i = 0; i < OCN_WPB; ++i) t += sh[i];
+    tile_sum[blockIdx.x] = t;
+  }
+}
+
+// one block: exclusive scan of tile_sum[0..nt) in place, tile_sum[nt] = total
+__global__ __launch_bounds__(OCN_BLOCK) void scan_spine(i64* tile_sum, i64 nt) {
+  __shared__ i64 sh[2 * OCN_WPB];
+  i64 carry = 0;
+  for (i64 c0 = 0; c0 < nt; c0 += OCN_BLOCK) {
+    i64 idx = c0 + threadIdx.x;
+    i64 v = idx < nt ? tile_sum[idx] : 0;
+    i64 tot;
+    i64 ex = block_excl_scan(v, sh, &tot);
+    if (idx < nt) tile_sum[idx] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) tile_sum[nt] = carry;
+}
+
+template <typename Op>
+__global__ __launch_bounds__(OCN_BLOCK) void scan_apply(Op op, i64 n, const i64* tile_sum, i64 nt,
+                                                        i64* out) {
+  __shared__ i64 sh[2 * OCN_WPB];
+  // thread-contiguous items so that the prefix order is the item order
+  const i64 base = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_IPT;
+  i64 v[SCAN_IPT];
+  i64 s = 0;
+#pragma unroll
+  for (int t = 0; t < SCAN_IPT; ++t) {
+    i64 e = base + t;
+    v[t] = e < n ? op(e) : 0;
+    s += v[t];
+  }
+  i64 tot;
+  i64 ex = block_excl_scan(s, sh, &tot) + tile_sum[blockIdx.x];
+#pragma unroll
+  for (int t = 0; t < SCAN_IPT; ++t) {
+    i64 e = base + t;
+    if (e < n) out[e] = ex;
+    ex += v[t];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_sum[nt];
+}
+
+template <typename Op>
+static int run_scan(Op op, i64 n, i64* out, void* ws, hipStream_t st) {
+  if (n < 0 || !out || !ws) return OCN_EINVAL;
+  i64 nt = (n + SCAN_TILE - 1) / SCAN_TILE;
+  if (nt == 0) nt = 1;
+  i64* tile_sum = (i64*)ws;
+  hipLaunchKernelGGL(scan_tile_sums<Op>, dim3((unsigned)nt), dim3(OCN_BLOCK), 0, st, op, n, tile_sum);
+  hipLaunchKernelGGL(scan_spine, dim3(1), dim3(OCN_BLOCK), 0, st, tile_sum, nt);
+  hipLaunchKernelGGL(scan_apply<Op>, dim3((unsigned)nt), dim3(OCN_BLOCK), 0, st, op, n, tile_sum, nt, out);
+  return launch_status();
+}
+
+extern "C" {
+
+int ocn_abi_version(void) { return OCN_ABI_VERSION; }
+
+int64_t ocn_scan_workspace_bytes(int64_t n) {
+  i64 nt = (n + SCAN_TILE - 1) / SCAN_TILE;
+  return (nt + 2) * (int64_t)sizeof(i64);
+}
+
+int ocn_edge_offsets(const int64_t* rowptrA, const int64_t* src, int64_t B, int64_t* off,
+                     void* workspace, void* stream) {
+  if (!rowptrA || (!src && B > 0)) return OCN_EINVAL;
+  DegOfSrc op{(const i64*)rowptrA, (const i64*)src};
+  return run_scan(op, B, (i64*)off, workspace, (hipStream_t)stream);
+}
+
+int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, void* stream) {
+  if (!in && n > 0) return OCN_EINVAL;
+  I32In op{in};
+  return run_scan(op, n, (i64*)out, workspace, (hipStream_t)stream);
+}
+
+}  // extern "C"

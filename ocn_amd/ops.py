@@ -70,56 +70,79 @@ def check_edges(src: Tensor, dst: Tensor, n_src: int, n_dst: int) -> None:
         raise IndexError("candidate edge endpoint out of range for the adjacency")
 
 
-def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Tuple[Tensor, Tensor], t2: Optional[Tuple[Tensor, Tensor]],
-             src: Tensor, dst: Tensor, n_cols: int, max_deg_a: int):
-    """Returns (off, flags, hist[N,4] int32, cnt1, cnt2|None, status)."""
+HIST_FIELD_BITS = 21             # hist word 0 packs n1 | n2 << 21 | n_union << 42
+MAX_BATCH = (1 << HIST_FIELD_BITS) - 1
+
+
+def hist_counts(hist: Tensor) -> Tensor:
+    """Decode the packed histogram [N,2] int64 into int64 [N,4] = {n1, n2, n_union, walks}."""
+    m = (1 << HIST_FIELD_BITS) - 1
+    p = hist[:, 0]
+    return torch.stack([p & m, (p >> HIST_FIELD_BITS) & m, (p >> (2 * HIST_FIELD_BITS)) & m, hist[:, 1]], dim=1)
+
+
+def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
+             t2: Optional[Tuple[Tensor, Tensor]], src: Tensor, dst: Tensor, n_cols: int, max_deg_a: int,
+             walk: bool = False):
+    """Intersection pass.  ``walk=False``: flags of N(src) against the rows of dst in t1 (and t2).
+    ``walk=True``: the pygho route on A itself (t1/t2 ignored): cn1 flags + walk counts.
+    Returns (off, flags, wc|None, hist[N,2] int64 packed, cnt1, cnt2|None, status)."""
     dev = src.device
     B = src.numel()
     _req(rowptrA, torch.int64, "rowptrA", 1); _req(colA, torch.int32, "colA", 1)
-    _req(t1[0], torch.int64, "rowptrT1", 1); _req(t1[1], torch.int32, "colT1", 1)
-    if t2 is not None:
-        _req(t2[0], torch.int64, "rowptrT2", 1); _req(t2[1], torch.int32, "colT2", 1)
+    if not walk:
+        _req(t1[0], torch.int64, "rowptrT1", 1); _req(t1[1], torch.int32, "colT1", 1)
+        if t2 is not None:
+            _req(t2[0], torch.int64, "rowptrT2", 1); _req(t2[1], torch.int32, "colT2", 1)
     _req(src, torch.int64, "src", 1); _req(dst, torch.int64, "dst", 1)
     if dst.numel() != B:
         raise ValueError("src/dst length mismatch")
+    if B > MAX_BATCH:
+        raise ValueError(f"candidate batch of {B} edges exceeds the histogram field width ({MAX_BATCH})")
     _mark("begin")
     off = edge_offsets(rowptrA, src)
     bound = B * max(int(max_deg_a), 0)
     cap = bound if bound <= FLAGS_NOSYNC_LIMIT else int(off[-1].item())
     flags = torch.empty(max(cap, 1), dtype=torch.uint8, device=dev)
-    hist = torch.zeros(n_cols, 4, dtype=torch.int32, device=dev)
+    wc = torch.empty(max(cap, 1), dtype=torch.int32, device=dev) if walk else None
+    hist = torch.zeros(n_cols, 2, dtype=torch.int64, device=dev)
     cnt1 = torch.empty(B, dtype=torch.int32, device=dev)
-    cnt2 = torch.empty(B, dtype=torch.int32, device=dev) if t2 is not None else None
+    cnt2 = torch.empty(B, dtype=torch.int32, device=dev) if (walk or t2 is not None) else None
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     _mark("cn_prep")
-    check(_lib.lib().ocn_cn_flags(ptr(rowptrA), ptr(colA), ptr(t1[0]), ptr(t1[1]),
-                                  ptr(t2[0] if t2 else None), ptr(t2[1] if t2 else None),
-                                  ptr(src), ptr(dst), B, ptr(off), ptr(flags), cap, ptr(hist),
-                                  ptr(cnt1), ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_flags")
+    if walk:
+        check(_lib.lib().ocn_cn_walk_flags(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), B, ptr(off), ptr(flags),
+                                           ptr(wc), cap, ptr(hist), ptr(cnt1), ptr(cnt2), ptr(status),
+                                           stream_ptr()), "ocn_cn_walk_flags")
+    else:
+        check(_lib.lib().ocn_cn_flags(ptr(rowptrA), ptr(colA), ptr(t1[0]), ptr(t1[1]),
+                                      ptr(t2[0] if t2 else None), ptr(t2[1] if t2 else None),
+                                      ptr(src), ptr(dst), B, ptr(off), ptr(flags), cap, ptr(hist),
+                                      ptr(cnt1), ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_flags")
     _mark("cn_flags")
-    return off, flags, hist, cnt1, cnt2, status
+    return off, flags, wc, hist, cnt1, cnt2, status
 
 
-def cn_weights_cn5(hist: Tensor, innerprod: Tensor) -> Tensor:
-    """In place: int32 [N,4] histogram -> float32 [N,4] weights (same storage)."""
-    _req(hist, torch.int32, "hist", 2)
+def cn_weights_cn5(hist: Tensor, innerprod: Tensor, valued: bool = False) -> Tensor:
+    """In place: packed int64 [N,2] histogram -> float32 [N,4] weights {w1, t, inv2, 0} (same storage)."""
+    _req(hist, torch.int64, "hist", 2)
     ip = _req(innerprod.detach().reshape(1).to(torch.float32), torch.float32, "innerprod", 1)
     scal = torch.zeros(4, dtype=torch.int32, device=hist.device)
-    check(_lib.lib().ocn_cn_weights_cn5(ptr(hist), hist.shape[0], ptr(ip), ptr(scal), stream_ptr()),
+    check(_lib.lib().ocn_cn_weights_cn5(ptr(hist), hist.shape[0], ptr(ip), ptr(scal), int(valued), stream_ptr()),
           "ocn_cn_weights_cn5")
     _mark("cn_weights")
     return hist.view(torch.float32)
 
 
 def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
-    _req(hist, torch.int32, "hist", 2)
+    _req(hist, torch.int64, "hist", 2)
     check(_lib.lib().ocn_cn_weights_cn7(ptr(hist), hist.shape[0], float(sum_fill), stream_ptr()),
           "ocn_cn_weights_cn7")
     _mark("cn_weights")
     return hist.view(torch.float32)
 
 
-def cn_gather(rowptrA, colA, src, dst, off, flags, weights: Tensor, h: Tensor):
+def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights: Tensor, h: Tensor):
     _req(weights, torch.float32, "weights", 2)
     _req(h, torch.float32, "h", 2)
     if weights.shape[0] != h.shape[0] or weights.shape[1] != 4:
@@ -127,7 +150,7 @@ def cn_gather(rowptrA, colA, src, dst, off, flags, weights: Tensor, h: Tensor):
     B, H = src.numel(), h.shape[1]
     out = torch.empty(3, B, H, dtype=torch.float32, device=h.device)
     check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), B, ptr(off), ptr(flags),
-                                   ptr(weights), ptr(h), H, ptr(out[0]), ptr(out[1]), ptr(out[2]),
+                                   ptr(wc), ptr(weights), ptr(h), H, ptr(out[0]), ptr(out[1]), ptr(out[2]),
                                    stream_ptr()), "ocn_cn_gather")
     _mark("cn_gather")
     return out[0], out[1], out[2]

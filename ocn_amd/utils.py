@@ -1,14 +1,15 @@
 """Drop-in for the hot-path names of the reference's ``utils.py``.
 
 ``adjoverlap`` (utils.py:248-285), ``PermIterator`` (utils.py:8-36), ``sparse_tensor_multiply`` /
-``block_matrix_multiply`` (utils.py:287-329) keep their signatures.  ``adjoverlap`` returns a lazy
-:class:`CNBatch` instead of a materialised [B, N] SparseTensor; the predictors in
-``ocn_amd.model`` recognise it and run the fused HIP path, ``.materialize()`` yields the explicit
-matrix (values 1.0) for inspection and parity tests.
+``block_matrix_multiply`` (utils.py:287-329) keep their signatures; ``get_cn1_cn2`` is the pygho
+route of the ppa / citation2 drivers (NeighborOverlap_large_ppa.py:147-173).  ``adjoverlap`` and
+``get_cn1_cn2`` return lazy :class:`CNBatch` handles instead of materialised [B, N] SparseTensors;
+the predictors in ``ocn_amd.model`` recognise them and run the fused HIP path, ``.materialize()``
+yields the explicit matrix for inspection and parity tests.
 """
 from __future__ import annotations
 
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -43,34 +44,44 @@ class PermIterator:
 
 class CNState:
     """Device state of one candidate batch after the intersection kernel: where each batch row
-    starts (``off``), one flag byte per neighbour of the source node, the per-column histograms
-    {n1, n2, n_union}, and the integer CN counts."""
+    starts (``off``), one flag byte per neighbour of the source node (bit 0: cn1 entry, bit 1: cn2
+    entry), the walk counts of the valued route, the packed per-column histograms
+    {n1, n2, n_union, walks}, and the integer CN counts."""
 
-    def __init__(self, adj: SparseTensor, t1: SparseTensor, t2: Optional[SparseTensor], tarei: Tensor):
+    def __init__(self, adj: SparseTensor, t1: Optional[SparseTensor], t2: Optional[SparseTensor],
+                 tarei: Tensor, walk: bool = False):
         if tarei.dim() != 2 or tarei.shape[0] != 2:
             raise ValueError("tarei must be [2, B]")
-        if t1.sparse_sizes() != adj.sparse_sizes() or (t2 is not None and t2.sparse_sizes() != adj.sparse_sizes()):
-            raise ValueError("adjoverlap: adjacency sizes differ")        # utils.py:164 assert
-        self.adj = adj
+        for t in (t1, t2):
+            if t is not None and t.sparse_sizes() != adj.sparse_sizes():
+                raise ValueError("adjoverlap: adjacency sizes differ")    # utils.py:164 assert
+        if walk and adj.size(0) != adj.size(1):
+            raise ValueError("get_cn1_cn2 needs a square adjacency")
+        self.adj, self.walk = adj, walk
         self.src = tarei[0].to(torch.int64).contiguous()
         self.dst = tarei[1].to(torch.int64).contiguous()
         self.B = self.src.numel()
         self.N = adj.size(1)
-        ops.check_edges(self.src, self.dst, adj.size(0), t1.size(0))
-        self.off, self.flags, self.hist, self.cnt1, self.cnt2, self.status = ops.cn_flags(
-            adj._rowptr, adj._col, (t1._rowptr, t1._col),
-            None if t2 is None else (t2._rowptr, t2._col), self.src, self.dst, self.N,
-            adj.max_rowcount())
+        ops.check_edges(self.src, self.dst, adj.size(0), adj.size(0) if walk else t1.size(0))
+        self.off, self.flags, self.wc, self.hist, self.cnt1, self.cnt2, self.status = ops.cn_flags(
+            adj._rowptr, adj._col, None if walk else (t1._rowptr, t1._col),
+            None if (walk or t2 is None) else (t2._rowptr, t2._col), self.src, self.dst, self.N,
+            adj.max_rowcount(), walk=walk)
         self._hist_live = True
 
     def check_status(self) -> None:
         if int(self.status.item()) != 0:
             raise RuntimeError("CN flag buffer capacity exceeded")
 
+    def hist_counts(self) -> Tensor:
+        """int64 [N, 4] = {n1, n2, n_union, walk-count sum} per column."""
+        assert self._hist_live, "histogram already consumed"
+        return ops.hist_counts(self.hist)
+
     def weights_cn5(self, innerprod: Tensor) -> Tensor:
         assert self._hist_live, "histogram already consumed"
         self._hist_live = False
-        return ops.cn_weights_cn5(self.hist, innerprod)
+        return ops.cn_weights_cn5(self.hist, innerprod, valued=self.walk)
 
     def weights_cn7(self, sum_fill: float) -> Tensor:
         assert self._hist_live, "histogram already consumed"
@@ -79,26 +90,29 @@ class CNState:
 
     def gather(self, weights: Tensor, h: Tensor):
         return ops.cn_gather(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off,
-                             self.flags, weights, h)
+                             self.flags, self.wc, weights, h)
 
     def materialize(self, bit: int) -> SparseTensor:
-        """[B, N] matrix of the entries whose flag has ``bit`` set, values 1.0 (host-side format
-        conversion for tests; not on the product path)."""
+        """[B, N] matrix of the entries whose flag has ``bit`` set; values 1.0, or the walk counts
+        for bit 2 of the valued route (host-side format conversion for tests; not on the product
+        path)."""
         row_sel = self.adj[self.src]
         r, c, _ = row_sel.coo()
-        order_off = row_sel._rowptr[:-1]
-        pos = torch.arange(r.numel(), device=r.device) - order_off[r] + self.off[:-1][r]
+        pos = torch.arange(r.numel(), device=r.device) - row_sel._rowptr[:-1][r] + self.off[:-1][r]
         keep = (self.flags[pos] & bit) != 0
-        return SparseTensor(row=r[keep], col=c[keep],
-                            value=torch.ones(int(keep.sum()), device=r.device),
-                            sparse_sizes=(self.B, self.N), is_sorted=True, trust_data=True)
+        val = torch.ones(int(keep.sum()), device=r.device)
+        if self.walk and bit == 2:
+            val = self.wc[pos][keep].to(torch.float32)
+        return SparseTensor(row=r[keep], col=c[keep], value=val, sparse_sizes=(self.B, self.N),
+                            is_sorted=True, trust_data=True)
 
 
 class CNBatch:
-    """Lazy ``adjoverlap(adj1, adj2, tarei)``: rows N_adj1(tarei[0][e]) ∩ N_adj2(tarei[1][e])."""
+    """Lazy ``adjoverlap(adj1, adj2, tarei)``: rows N_adj1(tarei[0][e]) ∩ N_adj2(tarei[1][e]); or one
+    half of ``get_cn1_cn2(adj, tedge)`` (``mode`` "walk1" / "walk2")."""
 
-    def __init__(self, adj1: SparseTensor, adj2: SparseTensor, tarei: Tensor):
-        self.adj1, self.adj2, self.tarei = adj1, adj2, tarei
+    def __init__(self, adj1: SparseTensor, adj2: Optional[SparseTensor], tarei: Tensor, mode: str = "pattern"):
+        self.adj1, self.adj2, self.tarei, self.mode = adj1, adj2, tarei, mode
         self._state: Optional[CNState] = None
 
     def sizes(self):
@@ -112,28 +126,37 @@ class CNBatch:
 
     def _single(self) -> CNState:
         if self._state is None:
-            self._state = CNState(self.adj1, self.adj2, None, self.tarei)
+            if self.mode == "pattern":
+                self._state = CNState(self.adj1, self.adj2, None, self.tarei)
+            else:
+                self._state = CNState(self.adj1, None, None, self.tarei, walk=True)
         return self._state
 
     def counts(self) -> Tensor:
-        """Integer CN count per candidate edge (per-row nnz of the reference's result)."""
-        return self._single().cnt1
+        """Integer CN count per candidate edge (per-row count of non-zero entries)."""
+        st = self._single()
+        return st.cnt2 if self.mode == "walk2" else st.cnt1
 
     def materialize(self) -> SparseTensor:
-        return self._single().materialize(1)
+        return self._single().materialize(2 if self.mode == "walk2" else 1)
 
 
 def fuse(cn1: CNBatch, cn2: CNBatch, tar_ei: Tensor) -> CNState:
     """One intersection pass for the (cn1, cn2) pair every driver builds from the same candidate
-    edges (NeighborOverlap_large.py:76-82,121-159)."""
+    edges (NeighborOverlap_large.py:76-82,121-159; NeighborOverlap_large_ppa.py:98-133)."""
     if not isinstance(cn1, CNBatch) or not isinstance(cn2, CNBatch):
-        raise TypeError("ocn_amd predictors take the CNBatch handles returned by ocn_amd.utils.adjoverlap")
+        raise TypeError("ocn_amd predictors take the CNBatch handles returned by ocn_amd.utils.adjoverlap "
+                        "/ get_cn1_cn2")
     if cn1.adj1 is not cn2.adj1:
         raise NotImplementedError("cn1 and cn2 must select their source rows from the same adjacency")
     if cn1.tarei.shape != cn2.tarei.shape or cn1.tarei.shape != tar_ei.shape:
         raise ValueError("cn1, cn2 and tar_ei describe different numbers of candidate edges")
     if ops.validate_indices and not (torch.equal(cn1.tarei, cn2.tarei) and torch.equal(cn1.tarei, tar_ei)):
         raise NotImplementedError("cn1, cn2 and tar_ei must be built from the same candidate edges")
+    if cn1.mode == "walk1" and cn2.mode == "walk2":
+        return CNState(cn1.adj1, None, None, cn1.tarei, walk=True)
+    if cn1.mode != "pattern" or cn2.mode != "pattern":
+        raise NotImplementedError("mixing adjoverlap and get_cn1_cn2 handles in one predictor call")
     return CNState(cn1.adj1, cn1.adj2, cn2.adj2, cn1.tarei)
 
 
@@ -144,6 +167,12 @@ def adjoverlap(adj1: SparseTensor, adj2: SparseTensor, tarei: Tensor, filled1: b
     if calresadj or cnsampledeg > 0 or ressampledeg > 0:
         raise NotImplementedError("calresadj / neighbour sampling are outside the cn5/cn7 path")
     return CNBatch(adj1, adj2, tarei)
+
+
+def get_cn1_cn2(adj: SparseTensor, tedge: Tensor) -> Tuple[CNBatch, CNBatch]:
+    """NeighborOverlap_large_ppa.py:147-173 / NeighborOverlapCitation2.py:78-104:
+    cn1 = Ei ⊙ Ej, cn2 = Ei ⊙ (Ej · A) with the number of 2-walks as values — no global A²."""
+    return CNBatch(adj, None, tedge, "walk1"), CNBatch(adj, None, tedge, "walk2")
 
 
 def block_matrix_multiply(spadj: SparseTensor, block_size: int) -> SparseTensor:

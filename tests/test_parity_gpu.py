@@ -59,7 +59,7 @@ def test_fused_flags_histograms(case):
     st.check_status()
     assert st.cnt1.cpu().tolist() == torch.bincount(case.ocn1.row, minlength=case.B).tolist()
     assert st.cnt2.cpu().tolist() == torch.bincount(case.ocn2.row, minlength=case.B).tolist()
-    hist = st.hist.cpu()
+    hist = st.hist_counts().cpu()
     assert hist[:, 0].tolist() == torch.bincount(case.ocn1.col, minlength=case.n).tolist()
     assert hist[:, 1].tolist() == torch.bincount(case.ocn2.col, minlength=case.n).tolist()
     union = torch.unique(torch.cat([O.spm2elem(case.ocn1), O.spm2elem(case.ocn2)]))
@@ -153,7 +153,8 @@ def test_appendix_c_on_gpu(hiplib):
     e = torch.tensor(g["batch"]).t().contiguous().to(DEV)
     st = CNState(adj, adj, adj2, e)
     assert st.cnt1.cpu().tolist() == g["cn1_counts"] and st.cnt2.cpu().tolist() == g["cn2_counts"]
-    assert st.hist[:, 0].cpu().tolist() == g["S1"] and st.hist[:, 1].cpu().tolist() == g["cn2_colsum"]
+    hc = st.hist_counts().cpu()
+    assert hc[:, 0].tolist() == g["S1"] and hc[:, 1].tolist() == g["cn2_colsum"]
     eye = torch.eye(4, device=DEV).repeat(1, 4).contiguous()           # H = 16, h[k] = one-hot(k) x4
     for key, ip in (("cn5_innerprod_0", 0.0), ("cn5_innerprod_0.37", 0.37)):
         st = CNState(adj, adj, adj2, e)
@@ -298,7 +299,7 @@ def test_properties_collab_shape(hiplib):
     e = sample_edges(r.cpu(), c.cpu(), n, 65536, seed=1).to(DEV)
     st = CNState(adj, adj, adj2, e)
     st.check_status()
-    hist = st.hist.clone()
+    hist = st.hist_counts()
     # histogram mass == per-edge counts; union between max and sum
     assert int(hist[:, 0].sum()) == int(st.cnt1.sum()) and int(hist[:, 1].sum()) == int(st.cnt2.sum())
     assert bool((hist[:, 2] <= hist[:, 0] + hist[:, 1]).all()) and bool((hist[:, 2] >= torch.maximum(hist[:, 0], hist[:, 1])).all())
@@ -308,7 +309,7 @@ def test_properties_collab_shape(hiplib):
     perm = torch.randperm(e.shape[1], device=DEV)
     st_p = CNState(adj, adj, adj2, e[:, perm].contiguous())
     assert torch.equal(st_p.cnt1, st.cnt1[perm]) and torch.equal(st_p.cnt2, st.cnt2[perm])
-    assert torch.equal(st_p.hist, hist)
+    assert torch.equal(st_p.hist_counts(), hist)
     # A² contains A's 2-walk closure: diagonal present for every non-isolated node, symmetric nnz
     deg = adj.storage.rowcount()
     r2, c2, _ = adj2.coo()
@@ -346,3 +347,53 @@ def test_rows_ln_relu_and_combine3(hiplib, H):
     c = torch.tensor([0.73, 0.41, -1.3], device=DEV)
     a1, a2, a3 = torch.randn(3, 1000, H, device=DEV)
     assert torch.equal(ops.combine3(c, a1, a2, a3), c[0] * a1 + c[1] * a2 + c[2] * a3)
+
+
+# ---- the pygho route: get_cn1_cn2 with walk-count values (ppa / citation2 drivers) -----------
+def test_walk_route_counts_values_and_pools(case):
+    from ocn_amd.utils import CNState, get_cn1_cn2
+    oc1, oc2 = O.get_cn1_cn2(case.oadj, case.e)
+    h1, h2 = get_cn1_cn2(case.adj, case.e.to(DEV))
+    assert h1.counts().cpu().tolist() == torch.bincount(oc1.row, minlength=case.B).tolist()
+    assert h2.counts().cpu().tolist() == torch.bincount(oc2.row, minlength=case.B).tolist()
+    assert spm_equal(h1.materialize(), oc1)
+    m2 = h2.materialize()
+    assert spm_equal(m2, oc2) and m2.storage.value().cpu().tolist() == oc2.val.tolist()
+    st = CNState(case.adj, None, None, case.e.to(DEV), walk=True)
+    hc = st.hist_counts().cpu()
+    assert hc[:, 0].tolist() == torch.bincount(oc1.col, minlength=case.n).tolist()
+    assert hc[:, 1].tolist() == torch.bincount(oc2.col, minlength=case.n).tolist()
+    assert hc[:, 3].tolist() == torch.zeros(case.n, dtype=torch.long).index_add_(0, oc2.col, oc2.val.long()).tolist()
+    x = torch.randn(case.n, 64, generator=torch.Generator().manual_seed(3))
+    for sum_fill in (0.0, 1.0):
+        r1, r2, _ = O.cn7_pool(x, oc1, oc2, sum_fill)
+        st = CNState(case.adj, None, None, case.e.to(DEV), walk=True)
+        g1, g2, _ = st.gather(st.weights_cn7(sum_fill), x.to(DEV))
+        assert torch.equal(g1.cpu(), r1) and torch.equal(g2.cpu(), r2)
+    for ip in (0.0, 0.37):
+        r1, r2, _ = O.cn5_pool(x, oc1, oc2, torch.tensor([ip]))
+        st = CNState(case.adj, None, None, case.e.to(DEV), walk=True)
+        g1, g2, _ = st.gather(st.weights_cn5(torch.tensor([ip], device=DEV)), x.to(DEV))
+        assert close(g1, r1)
+        tol = 1e-5 if ip == 0.0 else 2e-4
+        assert (g2.cpu() - r2).abs().max().item() <= tol * max(1.0, r2.abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["cn5", "cn7"])
+def test_walk_route_predictor_scores(case, name):
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import get_cn1_cn2
+    H = 32
+    torch.manual_seed(case.seed + 9)
+    x = torch.randn(case.n, H)
+    pred = predictor_dict[name](H, H, 1, 3, 0.0, 0.0, True, use_xlin=True, tailact=True).eval()
+    sd = {k: v.detach().clone() for k, v in pred.state_dict().items()}
+    oc1, oc2 = O.get_cn1_cn2(case.oadj, case.e)
+    args = SimpleNamespace(sum=1.0)
+    ref = (O.cn5_forward(sd, x, oc1, oc2, case.e, True, True) if name == "cn5"
+           else O.cn7_forward(sd, x, oc1, oc2, case.e, args.sum, True, True))
+    e = case.e.to(DEV)
+    c1, c2 = get_cn1_cn2(case.adj, e)
+    with torch.no_grad():
+        out = pred.to(DEV)(x.to(DEV), case.adj, c1, c2, e, args)
+    assert close(out, ref), (out.cpu() - ref).abs().max()
