@@ -49,8 +49,16 @@ __device__ __forceinline__ bool sampled_has(const int32_t* samp, const int32_t* 
 // K1 (pattern): flags for N(src) against the rows of dst in T1 (and T2)
 // ---------------------------------------------------------------------------------------------
 #define T1_CAP 256
+#ifndef OCN_X_G
+#define OCN_X_G 64     /* lanes per candidate edge; tools/kbench.py overrides it for timing experiments */
+#endif
 
-template <bool HAS_T2>
+// G lanes cooperate on one candidate edge (64/G edges per wave).  Measured on the collab-shaped
+// batch (tools/kbench.py): G = 64 / 32 / 16 / 8 -> 208 / 242 / 327 / 494 us.  The kernel is bound by
+// the number of distinct cache lines its scattered probes touch per wave instruction, not by the
+// latency of the chains: lanes that search the SAME rows share the top-of-tree lines, lanes of
+// different edges do not, so one edge per wave wins although most source rows are < 64 long.
+template <int G, bool HAS_T2>
 __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
     const i64* __restrict__ rowptrT1, const int32_t* __restrict__ colT1,
@@ -59,12 +67,13 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     const i64* __restrict__ off, uint8_t* __restrict__ flags, i64 cap,
     u64* __restrict__ hist, int32_t* __restrict__ cnt1, int32_t* __restrict__ cnt2,
     int32_t* __restrict__ status) {
-  __shared__ int32_t s_t1[OCN_WPB][T1_CAP];
-  __shared__ int32_t s_t2[OCN_WPB][OCN_WAVE];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int GPB = OCN_BLOCK / G;
+  __shared__ int32_t s_t1[GPB][T1_CAP];
+  __shared__ int32_t s_t2[GPB][OCN_WAVE];
+  const int gl = threadIdx.x % G, g = threadIdx.x / G;
   if (blockIdx.x == 0 && threadIdx.x == 0 && off[B] > cap) atomicOr(status, 1);
-  for (i64 e0 = (i64)blockIdx.x * OCN_WPB; e0 < B; e0 += (i64)gridDim.x * OCN_WPB) {
-    const i64 e = e0 + w;
+  for (i64 e0 = (i64)blockIdx.x * GPB; e0 < B; e0 += (i64)gridDim.x * GPB) {
+    const i64 e = e0 + g;
     const bool act = e < B;
     i64 a0 = 0, da = 0, b0 = 0, db = 0, c0 = 0, dc = 0, base = 0;
     if (act) {
@@ -74,32 +83,51 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
       if (HAS_T2) { c0 = rowptrT2[j]; dc = rowptrT2[j + 1] - c0; }
       base = off[e];
     }
-    // stage the short target row, and a 64-point sample of the long one, in this wave's LDS slice
+    // stage the short target row, and a 64-point sample of the long one, in this group's LDS slice
     const bool t1_lds = db <= T1_CAP;
     if (t1_lds)
-      for (i64 q = lane; q < db; q += OCN_WAVE) s_t1[w][q] = colT1[b0 + q];
+      for (i64 q = gl; q < db; q += G) s_t1[g][q] = colT1[b0 + q];
     if (HAS_T2) {
-      if (dc > OCN_WAVE) s_t2[w][lane] = colT2[c0 + (((i64)lane * dc) >> 6)];
-      else if (lane < dc) s_t2[w][lane] = colT2[c0 + lane];
+      if (dc > OCN_WAVE) {
+#pragma unroll
+        for (int q = gl; q < OCN_WAVE; q += G) s_t2[g][q] = colT2[c0 + (((i64)q * dc) >> 6)];
+      } else {
+        for (int q = gl; q < dc; q += G) s_t2[g][q] = colT2[c0 + q];
+      }
     }
     __syncthreads();
     const bool fits = base + da <= cap;
     int c1 = 0, c2 = 0;
-    for (i64 p = lane; p < da; p += OCN_WAVE) {
+    for (i64 p = gl; p < da; p += G) {
       const int32_t k = colA[a0 + p];
-      const bool f1 = t1_lds ? sorted_has(&s_t1[w][0], db, k) : sorted_has(colT1 + b0, db, k);
+#ifdef OCN_X_NOT1   /* OCN_X_*: timing experiments of tools/kbench.py, never defined in the product build */
+      const bool f1 = (k & 7) == 0;
+#else
+      const bool f1 = t1_lds ? sorted_has(&s_t1[g][0], db, k) : sorted_has(colT1 + b0, db, k);
+#endif
       bool f2 = false;
+#ifdef OCN_X_NOT2
+      f2 = (k & 1) == 0;
+#else
       if (HAS_T2)
-        f2 = dc > OCN_WAVE ? sampled_has(&s_t2[w][0], colT2 + c0, dc, k) : sorted_has(&s_t2[w][0], dc, k);
+        f2 = dc > OCN_WAVE ? sampled_has(&s_t2[g][0], colT2 + c0, dc, k) : sorted_has(&s_t2[g][0], dc, k);
+#endif
+#ifndef OCN_X_NOFLAGS
       if (fits) flags[base + p] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
+#endif
+#ifndef OCN_X_NOATOMIC
       if (f1 | f2)
         atomicAdd(hist + 2 * (i64)k, (u64)f1 | ((u64)f2 << HF_BITS) | (1ull << (2 * HF_BITS)));
+#endif
       c1 += f1;
       c2 += f2;
     }
-    c1 = wave_sum(c1);
-    c2 = wave_sum(c2);
-    if (act && lane == 0) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+      c1 += __shfl_xor(c1, o, OCN_WAVE);
+      c2 += __shfl_xor(c2, o, OCN_WAVE);
+    }
+    if (act && gl == 0) {
       cnt1[e] = c1;
       if (cnt2) cnt2[e] = c2;
     }
@@ -414,15 +442,16 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
   if (B == 0) return 0;
   if (!rowptrA || !rowptrT1 || !src || !dst || !off || !hist || !cnt1 || !status) return OCN_EINVAL;
   // col pointers may legitimately be NULL for an adjacency with no entries
-  const int grid = grid_for((B + OCN_WPB - 1) / OCN_WPB);
+  constexpr int GPB = OCN_BLOCK / OCN_X_G;
+  const int grid = grid_for((B + GPB - 1) / GPB);
   hipStream_t st = (hipStream_t)stream;
   if (rowptrT2)
-    hipLaunchKernelGGL(cn_flags_kernel<true>, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
+    hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, true>), dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
                        colA, (const i64*)rowptrT1, colT1, (const i64*)rowptrT2, colT2, (const i64*)src,
                        (const i64*)dst, (i64)B, (const i64*)off, flags, (i64)flags_cap, (u64*)hist, cnt1,
                        cnt2, status);
   else
-    hipLaunchKernelGGL(cn_flags_kernel<false>, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
+    hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, false>), dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
                        colA, (const i64*)rowptrT1, colT1, (const i64*)nullptr, (const int32_t*)nullptr,
                        (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, (i64)flags_cap,
                        (u64*)hist, cnt1, cnt2, status);
