@@ -136,6 +136,21 @@ int ocn_rows_ln_relu(const float* x, const float* gamma, const float* beta, floa
 int ocn_combine3(const float* coef, const float* x1, const float* x2, const float* x3, int64_t n,
                  float* out, void* stream);
 
+/* The nn.Linear layers of the heads (model.py:2192-2235) on the matrix cores:
+ *   Y[M][N] = epilogue(X[M][K] . W^T + bias),  X/W/Y fp32, W = nn.Linear.weight [N][K].
+ * Each fp32 operand is split into three bf16 terms and the six leading cross products are
+ * accumulated in fp32 on v_mfma_f32_32x32x16_bf16 (error below fp32's own rounding).
+ * ocn_linear_split_weight writes the pre-split, fragment-ordered panel Wp
+ * (ocn_linear_panel_bytes(N, K) bytes; redo it whenever W changes).  N in {32,64,128,256}, K % 16 == 0.
+ * Epilogue, in this order: + bias (or NULL); LayerNorm over the N columns with gamma/beta/eps (or
+ * both NULL); ReLU if relu != 0; then either store Y[M][N], or — when dotw != NULL — the trailing
+ * Linear(N -> 1) of `lin`: Y[M] = <row, dotw> + dotb[0]. */
+int64_t ocn_linear_panel_bytes(int32_t N, int32_t K);
+int ocn_linear_split_weight(const float* W, int32_t N, int32_t K, void* Wp, void* stream);
+int ocn_linear_bf16x6(const float* X, int64_t M, int32_t K, const void* Wp, int32_t N,
+                      const float* bias, const float* gamma, const float* beta, float eps,
+                      int32_t relu, const float* dotw, const float* dotb, float* Y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

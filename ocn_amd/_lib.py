@@ -36,6 +36,10 @@ SIGNATURES = {
     "ocn_spgemm_pattern_fill": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, _P]),
     "ocn_rows_ln_relu": (c_int32, [_P, _P, _P, c_float, c_int32, c_int64, c_int32, _P, _P]),
     "ocn_combine3": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P]),
+    "ocn_linear_panel_bytes": (c_int64, [c_int32, c_int32]),
+    "ocn_linear_split_weight": (c_int32, [_P, c_int32, c_int32, _P, _P]),
+    "ocn_linear_bf16x6": (c_int32, [_P, c_int64, c_int32, _P, c_int32, _P, _P, _P, c_float, c_int32, _P, _P,
+                                    _P, _P]),
 }
 
 

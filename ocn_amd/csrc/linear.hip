@@ -1,0 +1,236 @@
+// Dense Linear layers of the MLP heads (model.py:2203-2235) on the gfx950 matrix cores.
+//
+//   Y[M,N] = epilogue( X[M,K] · Wᵀ + bias )        X, W, Y fp32; W is nn.Linear's [N][K]
+//
+// fp32 operands are split into three bf16 terms each (x = x1 + x2 + x3 to 2^-27 relative) and the
+// product is formed from the six leading cross terms on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation ("bf16x6"): the dropped terms are below 2^-26 of |x||w|, i.e. under fp32's own
+// rounding, at 6/16 of the cost of the f32-input MFMA.  This is the one MFMA-shaped piece of the
+// path.
+//
+// Tiling: a workgroup = 4 waves = 128 rows; each wave owns 32 full rows x all N columns, so the
+// LayerNorm / ReLU / final-dot epilogues are row-local (in-wave shuffles, no LDS).  X fragments go
+// straight from memory to registers (each element is used by exactly one wave); the pre-split,
+// fragment-ordered weight panel of each 16-deep k-step is staged in LDS and shared by the 4 waves.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define LIN_KS 16                    // k per MFMA step
+#define LIN_ROWS 128                 // rows per workgroup
+
+__device__ __forceinline__ float bf16_to_f32(__bf16 v) {
+  return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, v) << 16);
+}
+
+// x = p1 + p2 + p3 (+ O(2^-27 |x|)), each term a bf16 (round to nearest even)
+__device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
+  p1 = (__bf16)x;
+  const float r1 = x - bf16_to_f32(p1);
+  p2 = (__bf16)r1;
+  const float r2 = r1 - bf16_to_f32(p2);
+  p3 = (__bf16)r2;
+}
+
+// Wp[s][t][split][lane][8]: the B fragment (k = 16s + 8(lane>>5) + j, n = 32t + (lane&31)) of
+// split `split`, so that one k-step's panel is a contiguous, lane-linear LDS image.
+__global__ __launch_bounds__(OCN_BLOCK) void split_weight_kernel(const float* __restrict__ W, int N, int K,
+                                                                 __bf16* __restrict__ Wp) {
+  const int NT = N >> 5;
+  const i64 total = (i64)(K / LIN_KS) * NT * 64;           // fragments
+  for (i64 f = (i64)blockIdx.x * blockDim.x + threadIdx.x; f < total; f += (i64)gridDim.x * blockDim.x) {
+    const int lane = (int)(f & 63);
+    const int t = (int)((f >> 6) % NT);
+    const int s = (int)((f >> 6) / NT);
+    const float* src = W + (i64)(32 * t + (lane & 31)) * K + LIN_KS * s + 8 * (lane >> 5);
+    bf16x8 p[3];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __bf16 a, b, c;
+      split3(src[j], a, b, c);
+      p[0][j] = a; p[1][j] = b; p[2][j] = c;
+    }
+    bf16x8* dst = reinterpret_cast<bf16x8*>(Wp) + ((i64)(s * NT + t) * 3) * 64 + lane;
+    dst[0] = p[0];
+    dst[64] = p[1];
+    dst[128] = p[2];
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
+    const float* __restrict__ X, i64 M, int K, const __bf16* __restrict__ Wp,
+    const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float eps, int relu, const float* __restrict__ dotw, const float* __restrict__ dotb,
+    float* __restrict__ Y) {
+  constexpr int N = NT * 32;
+  constexpr int PANEL = NT * 3 * 64;                      // bf16x8 fragments per k-step panel
+  __shared__ __attribute__((aligned(16))) bf16x8 wbuf[2][PANEL];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const i64 row0 = (i64)blockIdx.x * LIN_ROWS + 32 * w;
+  i64 arow = row0 + r;
+  if (arow >= M) arow = M - 1;                            // tail rows: load something valid, never store
+  const float4* xrow = reinterpret_cast<const float4*>(X + arow * K + 8 * hh);
+  const bf16x8* wp8 = reinterpret_cast<const bf16x8*>(Wp);
+  const int nks = K / LIN_KS;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // prologue: panel 0 -> LDS, X fragment 0 -> registers
+  for (int f = threadIdx.x; f < PANEL; f += OCN_BLOCK) wbuf[0][f] = wp8[f];
+  float4 xa = xrow[0], xb = xrow[1];
+  __syncthreads();
+
+  for (int s = 0; s < nks; ++s) {
+    const int cur = s & 1;
+    // next panel and next X fragment in flight while this step computes
+    bf16x8 stage[(PANEL + OCN_BLOCK - 1) / OCN_BLOCK];
+    float4 na = xa, nb = xb;
+    if (s + 1 < nks) {
+#pragma unroll
+      for (int q = 0; q < (PANEL + OCN_BLOCK - 1) / OCN_BLOCK; ++q) {
+        const int f = threadIdx.x + q * OCN_BLOCK;
+        if (f < PANEL) stage[q] = wp8[(i64)(s + 1) * PANEL + f];
+      }
+      na = xrow[(s + 1) * (LIN_KS / 4)];
+      nb = xrow[(s + 1) * (LIN_KS / 4) + 1];
+    }
+    bf16x8 a1, a2, a3;
+    {
+      const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __bf16 p, q, u;
+        split3(xs[j], p, q, u);
+        a1[j] = p; a2[j] = q; a3[j] = u;
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const bf16x8 b1 = wbuf[cur][(t * 3 + 0) * 64 + lane];
+      const bf16x8 b2 = wbuf[cur][(t * 3 + 1) * 64 + lane];
+      const bf16x8 b3 = wbuf[cur][(t * 3 + 2) * 64 + lane];
+      // smallest cross terms first
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+    }
+    if (s + 1 < nks) {
+#pragma unroll
+      for (int q = 0; q < (PANEL + OCN_BLOCK - 1) / OCN_BLOCK; ++q) {
+        const int f = threadIdx.x + q * OCN_BLOCK;
+        if (f < PANEL) wbuf[cur ^ 1][f] = stage[q];
+      }
+    }
+    xa = na; xb = nb;
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds column c = 32t + r of rows (i&3) + 8(i>>2) + 4hh, i = 0..15 ----
+  if (bias) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float bv = bias[32 * t + r];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] += bv;
+    }
+  }
+  if (gamma) {
+    float g[NT], be[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { g[t] = gamma[32 * t + r]; be[t] = beta[32 * t + r]; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float sum = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) sum += acc[t][i];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, OCN_WAVE);
+      const float mean = sum / (float)N;
+      float q = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { const float d = acc[t][i] - mean; q += d * d; }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, OCN_WAVE);
+      const float rstd = 1.0f / sqrtf(q / (float)N + eps);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][i] = (acc[t][i] - mean) * rstd * g[t] + be[t];
+    }
+  }
+  if (relu) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = fmaxf(acc[t][i], 0.f);
+  }
+  if (dotw) {
+    // trailing Linear(N -> 1): y[row] = <row, dotw> + dotb, one float per row
+    float wv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wv[t] = dotw[32 * t + r];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float d = 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) d += acc[t][i] * wv[t];
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) d += __shfl_xor(d, o, OCN_WAVE);
+      const i64 row = row0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (r == 0 && row < M) Y[row] = d + (dotb ? dotb[0] : 0.f);
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const i64 row = row0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+    if (row < M) {
+      float* yr = Y + row * N + r;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) yr[32 * t] = acc[t][i];
+    }
+  }
+}
+
+extern "C" {
+
+int64_t ocn_linear_panel_bytes(int32_t N, int32_t K) { return (int64_t)N * K * 3 * 2; }
+
+int ocn_linear_split_weight(const float* W, int32_t N, int32_t K, void* Wp, void* stream) {
+  if (!W || !Wp || N <= 0 || K <= 0 || (N & 31) || (K % LIN_KS)) return OCN_EINVAL;
+  const i64 frags = (i64)(K / LIN_KS) * (N >> 5) * 64;
+  hipLaunchKernelGGL(split_weight_kernel, dim3(grid_for((frags + OCN_BLOCK - 1) / OCN_BLOCK, 1024)),
+                     dim3(OCN_BLOCK), 0, (hipStream_t)stream, W, (int)N, (int)K, (__bf16*)Wp);
+  return launch_status();
+}
+
+#define LAUNCH_LINEAR(NT)                                                                           \
+  hipLaunchKernelGGL((linear_bf16x6_kernel<NT>), dim3((unsigned)((M + LIN_ROWS - 1) / LIN_ROWS)),   \
+                     dim3(OCN_BLOCK), 0, (hipStream_t)stream, X, (i64)M, (int)K, (const __bf16*)Wp, \
+                     bias, gamma, beta, eps, (int)relu, dotw, dotb, Y)
+
+int ocn_linear_bf16x6(const float* X, int64_t M, int32_t K, const void* Wp, int32_t N,
+                      const float* bias, const float* gamma, const float* beta, float eps,
+                      int32_t relu, const float* dotw, const float* dotb, float* Y, void* stream) {
+  if (M < 0 || K <= 0 || (K % LIN_KS) || N <= 0) return OCN_EINVAL;
+  if (M == 0) return 0;
+  if (!X || !Wp || !Y || ((gamma == nullptr) != (beta == nullptr))) return OCN_EINVAL;
+  switch (N) {
+    case 32:  LAUNCH_LINEAR(1); break;
+    case 64:  LAUNCH_LINEAR(2); break;
+    case 128: LAUNCH_LINEAR(4); break;
+    case 256: LAUNCH_LINEAR(8); break;
+    default: return OCN_EINVAL;
+  }
+  return launch_status();
+}
+
+}  // extern "C"

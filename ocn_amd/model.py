@@ -270,13 +270,30 @@ class GCN3(_Encoder):
 # predictors
 # ------------------------------------------------------------------------------------------
 def _seq_eval(seq: nn.Sequential, x: Tensor) -> Tensor:
-    """Eval-mode walk of one of the predictor's ``nn.Sequential`` heads: Dropout/Identity vanish,
-    ``LayerNorm -> ReLU`` becomes one HIP pass (in place on the Linear's fresh output)."""
+    """Eval-mode walk of one of the predictor's ``nn.Sequential`` heads.  Dropout/Identity vanish;
+    ``Linear [-> LayerNorm] [-> ReLU] [-> Linear(H, 1)]`` runs as one bf16x6 MFMA kernel with the
+    tail fused into its epilogue; anything that does not fit falls back to the module itself (the
+    remaining ``LayerNorm -> ReLU`` pairs still as one HIP pass)."""
     mods = [m for m in seq if not isinstance(m, (nn.Dropout, nn.Identity))]
     fresh, i = False, 0
     while i < len(mods):
         m = mods[i]
-        if (isinstance(m, nn.LayerNorm) and m.elementwise_affine and x.dim() == 2
+        if isinstance(m, nn.Linear) and ops.linear_ok(x, m.weight):
+            j, ln, relu, dot = i + 1, None, False, None
+            if (j < len(mods) and isinstance(mods[j], nn.LayerNorm) and mods[j].elementwise_affine
+                    and tuple(mods[j].normalized_shape) == (m.out_features,)):
+                ln = (mods[j].weight, mods[j].bias, mods[j].eps)
+                j += 1
+            if j < len(mods) and isinstance(mods[j], nn.ReLU):
+                relu = True
+                j += 1
+            if (j == len(mods) - 1 and isinstance(mods[j], nn.Linear) and mods[j].out_features == 1
+                    and mods[j].in_features == m.out_features):
+                dot = (mods[j].weight, mods[j].bias)
+                j += 1
+            x = ops.linear(x, m.weight, m.bias, ln, relu, dot)
+            i = j
+        elif (isinstance(m, nn.LayerNorm) and m.elementwise_affine and x.dim() == 2
                 and x.shape[-1] in ops.LN_WIDTHS and x.is_contiguous()):
             relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
             x = ops.rows_ln_relu(x, m.weight, m.bias, m.eps, relu, inplace=fresh)
@@ -289,7 +306,6 @@ def _seq_eval(seq: nn.Sequential, x: Tensor) -> Tensor:
             i += 1
         fresh = True
     return x
-
 
 
 class _CNPredictorBase(nn.Module):

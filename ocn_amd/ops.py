@@ -236,3 +236,57 @@ def combine3(coef: Tensor, x1: Tensor, x2: Tensor, x3: Tensor) -> Tensor:
     check(_lib.lib().ocn_combine3(ptr(coef), ptr(x1), ptr(x2), ptr(x3), x1.numel(), ptr(out), stream_ptr()),
           "ocn_combine3")
     return out
+
+
+LINEAR_WIDTHS = (32, 64, 128, 256)
+fast_linear = True               # route eligible nn.Linear layers of the heads through ocn_linear_bf16x6
+_panels: dict = {}
+
+
+def linear_panel(weight: Tensor) -> Tensor:
+    """Pre-split, fragment-ordered bf16 panel of an nn.Linear weight.  Cached per live tensor object
+    (weak reference) and rebuilt when the weight is modified in place (``_version``), re-pointed
+    (``data_ptr``) or reshaped — a freed weight's address being reused by another module must not
+    hit."""
+    import weakref
+    key = id(weight)
+    hit = _panels.get(key)
+    if (hit is not None and hit[0]() is weight and hit[1] == weight.data_ptr() and hit[2] == weight._version
+            and hit[3] == tuple(weight.shape)):
+        return hit[4]
+    w = _req(weight.detach(), torch.float32, "weight", 2)
+    N, K = w.shape
+    panel = torch.empty(int(_lib.lib().ocn_linear_panel_bytes(N, K)), dtype=torch.uint8, device=w.device)
+    check(_lib.lib().ocn_linear_split_weight(ptr(w), N, K, ptr(panel), stream_ptr()), "ocn_linear_split_weight")
+    if len(_panels) > 512:
+        for k in [k for k, v in _panels.items() if v[0]() is None]:
+            del _panels[k]
+    _panels[key] = (weakref.ref(weight), weight.data_ptr(), weight._version, (N, K), panel)
+    return panel
+
+
+def linear_ok(x: Tensor, weight: Tensor) -> bool:
+    return (fast_linear and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous()
+            and weight.shape[0] in LINEAR_WIDTHS and weight.shape[1] % 16 == 0 and weight.shape[1] == x.shape[1])
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln=None, relu: bool = False,
+           dot=None) -> Tensor:
+    """epilogue(x @ weight.T + bias): optional LayerNorm ``ln=(gamma, beta, eps)``, ReLU, and a
+    trailing Linear(N -> 1) ``dot=(w[1,N], b[1] | None)`` (then the result is [M, 1])."""
+    _req(x, torch.float32, "x", 2)
+    M, K = x.shape
+    N = weight.shape[0]
+    panel = linear_panel(weight)
+    y = torch.empty((M, 1) if dot is not None else (M, N), dtype=torch.float32, device=x.device)
+    g = b = None
+    eps = 0.0
+    if ln is not None:
+        g, b, eps = ln
+    dw = db = None
+    if dot is not None:
+        dw, db = dot
+        dw = dw.reshape(-1)
+    check(_lib.lib().ocn_linear_bf16x6(ptr(x), M, K, ptr(panel), N, ptr(bias), ptr(g), ptr(b), float(eps),
+                                       int(relu), ptr(dw), ptr(db), ptr(y), stream_ptr()), "ocn_linear_bf16x6")
+    return y

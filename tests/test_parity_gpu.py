@@ -397,3 +397,31 @@ def test_walk_route_predictor_scores(case, name):
     with torch.no_grad():
         out = pred.to(DEV)(x.to(DEV), case.adj, c1, c2, e, args)
     assert close(out, ref), (out.cpu() - ref).abs().max()
+
+
+# ---- bf16x6 MFMA Linear (floating point: plain torch fp32 reference, fp64 ground truth) --------
+@pytest.mark.parametrize("M,K,N", [(1, 16, 32), (300, 64, 64), (1000, 256, 256), (4099, 128, 256), (257, 256, 128)])
+def test_linear_bf16x6(hiplib, M, K, N):
+    from ocn_amd import ops
+    torch.manual_seed(M + N)
+    x = (torch.randn(M, K) * 2).to(DEV)
+    lin = torch.nn.Linear(K, N).to(DEV)
+    ln = torch.nn.LayerNorm(N).to(DEV)
+    with torch.no_grad():
+        ln.weight.normal_(); ln.bias.normal_()
+        out1 = torch.nn.Linear(N, 1).to(DEV)
+        exact = (x.double() @ lin.weight.double().t() + lin.bias.double())
+        ref32 = torch.nn.functional.linear(x, lin.weight, lin.bias)
+        got = ops.linear(x, lin.weight, lin.bias)
+        scale = exact.abs().max().item()
+        err_mine, err_f32 = (got.double() - exact).abs().max().item(), (ref32.double() - exact).abs().max().item()
+        assert err_mine <= max(2.0 * err_f32, 2e-7 * scale), (err_mine, err_f32)      # as accurate as an fp32 GEMM
+        assert torch.allclose(got, ref32, atol=2e-6 * scale, rtol=1e-5)
+        assert torch.equal(ops.linear(x, lin.weight, None, relu=True), torch.relu(ops.linear(x, lin.weight)))
+        y = torch.relu(ln(ref32))
+        assert torch.allclose(ops.linear(x, lin.weight, lin.bias, (ln.weight, ln.bias, ln.eps), True), y, atol=1e-5, rtol=1e-5)
+        d = ops.linear(x, lin.weight, lin.bias, (ln.weight, ln.bias, ln.eps), True, (out1.weight, out1.bias))
+        assert d.shape == (M, 1) and torch.allclose(d, out1(y), atol=2e-5, rtol=1e-5)
+        lin.weight.mul_(2.0)                                                          # in-place update -> panel rebuilt
+        assert torch.allclose(ops.linear(x, lin.weight, lin.bias), torch.nn.functional.linear(x, lin.weight, lin.bias),
+                              atol=4e-6 * scale, rtol=1e-5)
