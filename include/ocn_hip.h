@@ -43,6 +43,14 @@ int64_t ocn_scan_workspace_bytes(int64_t n);
 int ocn_edge_offsets(const int64_t* rowptrA, const int64_t* src, int64_t B,
                      int64_t* off, void* workspace, void* stream);
 
+/* A processing order for a candidate batch: order[] = the batch rows counting-sorted by the node id
+ * in `node` (arbitrary order among equal ids).  Visiting rows with the same / nearby source node
+ * together lets the rows they share be served from L2; it never changes a result.
+ * workspace: ocn_order_workspace_bytes(n_nodes) bytes of device scratch. */
+int64_t ocn_order_workspace_bytes(int64_t n_nodes);
+int ocn_order_by_node(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* order, void* workspace,
+                      void* stream);
+
 /* Exclusive scan of int32 counts into int64 offsets (out[n] = total). */
 int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, void* stream);
 
@@ -53,11 +61,14 @@ int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, vo
  * histograms are accumulated (cn.sum(dim=0), model.py:2261,3114): hist[k] = {packed, walks}
  * with packed = n1 | n2 << 21 | n_union << 42 (one 64-bit atomic per CN entry) and walks = 0
  * here; must be zero on entry; B < 2^21.  T2 may be NULL (single adjoverlap call).
- * status: device int32, bit 0 set if off[B] > flags_cap (nothing is written past the cap). */
+ * status: device int32, bit 0 set if off[B] > flags_cap (nothing is written past the cap).
+ * order (here and below): optional permutation of 0..B-1 giving the order in which the batch rows
+ * are PROCESSED (e.g. sorted by src so that rows sharing neighbourhoods meet in L2); every output
+ * stays indexed by the batch row.  NULL = batch order. */
 int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA,
                  const int64_t* rowptrT1, const int32_t* colT1,
                  const int64_t* rowptrT2, const int32_t* colT2,
-                 const int64_t* src, const int64_t* dst, int64_t B,
+                 const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                  const int64_t* off, uint8_t* flags, int64_t flags_cap,
                  uint64_t* hist /* [N][2] */, int32_t* cnt1, int32_t* cnt2,
                  int32_t* status, void* stream);
@@ -68,7 +79,7 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA,
  * additionally accumulates walks = sum of the counts of column k; cnt2[e] = number of non-zero
  * entries of cn2 row e. */
 int ocn_cn_walk_flags(const int64_t* rowptrA, const int32_t* colA,
-                      const int64_t* src, const int64_t* dst, int64_t B,
+                      const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                       const int64_t* off, uint8_t* flags, int32_t* wc, int64_t flags_cap,
                       uint64_t* hist /* [N][2] */, int32_t* cnt1, int32_t* cnt2,
                       int32_t* status, void* stream);
@@ -93,7 +104,7 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream);
  * multiply then add.  wc = per-neighbour cn2 values of the walk route or NULL (all 1.0).
  * h is [N][H] row-major fp32; outputs [B][H]. */
 int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA,
-                  const int64_t* src, const int64_t* dst, int64_t B,
+                  const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                   const int64_t* off, const uint8_t* flags, const int32_t* wc,
                   const float* weights /* [N][4] */, const float* h, int32_t H,
                   float* xcn1, float* xcn2, float* xij, void* stream);

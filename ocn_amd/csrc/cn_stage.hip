@@ -63,7 +63,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
     const i64* __restrict__ rowptrT1, const int32_t* __restrict__ colT1,
     const i64* __restrict__ rowptrT2, const int32_t* __restrict__ colT2,
-    const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
+    const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     const i64* __restrict__ off, uint8_t* __restrict__ flags, i64 cap,
     u64* __restrict__ hist, int32_t* __restrict__ cnt1, int32_t* __restrict__ cnt2,
     int32_t* __restrict__ status) {
@@ -73,8 +73,9 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
   const int gl = threadIdx.x % G, g = threadIdx.x / G;
   if (blockIdx.x == 0 && threadIdx.x == 0 && off[B] > cap) atomicOr(status, 1);
   for (i64 e0 = (i64)blockIdx.x * GPB; e0 < B; e0 += (i64)gridDim.x * GPB) {
-    const i64 e = e0 + g;
-    const bool act = e < B;
+    const i64 slot = e0 + g;                  // processing slot; `order` maps it to a batch row
+    const bool act = slot < B;
+    const i64 e = act ? (order ? order[slot] : slot) : 0;
     i64 a0 = 0, da = 0, b0 = 0, db = 0, c0 = 0, dc = 0, base = 0;
     if (act) {
       const i64 i = src[e], j = dst[e];
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
 
 __global__ __launch_bounds__(OCN_BLOCK) void cn_walk_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
-    const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
+    const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     const i64* __restrict__ off, uint8_t* __restrict__ flags, int32_t* __restrict__ wc, i64 cap,
     u64* __restrict__ hist, int32_t* __restrict__ cnt1, int32_t* __restrict__ cnt2,
     int32_t* __restrict__ status) {
@@ -151,8 +152,9 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_walk_kernel(
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (blockIdx.x == 0 && threadIdx.x == 0 && off[B] > cap) atomicOr(status, 1);
   for (i64 e0 = (i64)blockIdx.x * OCN_WPB; e0 < B; e0 += (i64)gridDim.x * OCN_WPB) {
-    const i64 e = e0 + w;
-    const bool act = e < B;
+    const i64 slot = e0 + w;
+    const bool act = slot < B;
+    const i64 e = act ? (order ? order[slot] : slot) : 0;
     i64 a0 = 0, da = 0, b0 = 0, db = 0, base = 0;
     if (act) {
       const i64 i = src[e], j = dst[e];
@@ -303,7 +305,7 @@ __device__ __forceinline__ void entry_weights(unsigned f, const float4& w, float
 template <int LPE, int NV>
 __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
-    const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
+    const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
     float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
@@ -312,8 +314,9 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
   const int lane = threadIdx.x & 63;
   const int gl = lane % LPE;
   const int gbase = lane - gl;
-  const i64 e = ((i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
-  if (e >= B) return;                       // whole group leaves together
+  const i64 slot = ((i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
+  if (slot >= B) return;                    // whole group leaves together
+  const i64 e = order ? order[slot] : slot;
   const i64 i = src[e], j = dst[e];
   const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
   const i64 base = off[e];
@@ -386,13 +389,14 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
 // any H: one wave per edge, one feature per lane per 64-wide chunk (re-walks the flags per chunk)
 __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_generic(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
-    const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
+    const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
     float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
   const int lane = threadIdx.x & 63;
-  const i64 e = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6);
-  if (e >= B) return;
+  const i64 slot = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6);
+  if (slot >= B) return;
+  const i64 e = order ? order[slot] : slot;
   const i64 i = src[e], j = dst[e];
   const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
   const i64 base = off[e];
@@ -435,9 +439,9 @@ extern "C" {
 
 int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* rowptrT1,
                  const int32_t* colT1, const int64_t* rowptrT2, const int32_t* colT2,
-                 const int64_t* src, const int64_t* dst, int64_t B, const int64_t* off,
-                 uint8_t* flags, int64_t flags_cap, uint64_t* hist, int32_t* cnt1, int32_t* cnt2,
-                 int32_t* status, void* stream) {
+                 const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
+                 const int64_t* off, uint8_t* flags, int64_t flags_cap, uint64_t* hist, int32_t* cnt1,
+                 int32_t* cnt2, int32_t* status, void* stream) {
   if (B < 0 || flags_cap < 0 || B > (int64_t)HF_MASK) return OCN_EINVAL;
   if (B == 0) return 0;
   if (!rowptrA || !rowptrT1 || !src || !dst || !off || !hist || !cnt1 || !status) return OCN_EINVAL;
@@ -448,18 +452,18 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
   if (rowptrT2)
     hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, true>), dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
                        colA, (const i64*)rowptrT1, colT1, (const i64*)rowptrT2, colT2, (const i64*)src,
-                       (const i64*)dst, (i64)B, (const i64*)off, flags, (i64)flags_cap, (u64*)hist, cnt1,
+                       (const i64*)dst, (const i64*)order, (i64)B, (const i64*)off, flags, (i64)flags_cap, (u64*)hist, cnt1,
                        cnt2, status);
   else
     hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, false>), dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
                        colA, (const i64*)rowptrT1, colT1, (const i64*)nullptr, (const int32_t*)nullptr,
-                       (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, (i64)flags_cap,
-                       (u64*)hist, cnt1, cnt2, status);
+                       (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, (const i64*)off, flags,
+                       (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
   return launch_status();
 }
 
 int ocn_cn_walk_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
-                      const int64_t* dst, int64_t B, const int64_t* off, uint8_t* flags, int32_t* wc,
+                      const int64_t* dst, const int64_t* order, int64_t B, const int64_t* off, uint8_t* flags, int32_t* wc,
                       int64_t flags_cap, uint64_t* hist, int32_t* cnt1, int32_t* cnt2, int32_t* status,
                       void* stream) {
   if (B < 0 || flags_cap < 0 || B > (int64_t)HF_MASK) return OCN_EINVAL;
@@ -468,8 +472,8 @@ int ocn_cn_walk_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t
   if (flags_cap > 0 && (!flags || !wc)) return OCN_EINVAL;
   const int grid = grid_for((B + OCN_WPB - 1) / OCN_WPB);
   hipLaunchKernelGGL(cn_walk_kernel, dim3(grid), dim3(OCN_BLOCK), 0, (hipStream_t)stream,
-                     (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off,
-                     flags, wc, (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
+                     (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B,
+                     (const i64*)off, flags, wc, (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
   return launch_status();
 }
 
@@ -495,7 +499,7 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream) 
   return launch_status();
 }
 
-#define GATHER_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, \
+#define GATHER_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, (const i64*)off, \
                     flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij
 #define LAUNCH_GATHER(LPE, NV)                                                                      \
   do {                                                                                              \
@@ -505,7 +509,7 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream) 
   } while (0)
 
 int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
-                  const int64_t* dst, int64_t B, const int64_t* off, const uint8_t* flags,
+                  const int64_t* dst, const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
                   const int32_t* wc, const float* weights, const float* h, int32_t H, float* xcn1,
                   float* xcn2, float* xij, void* stream) {
   if (B < 0 || H <= 0) return OCN_EINVAL;

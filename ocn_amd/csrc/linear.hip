@@ -19,6 +19,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define LIN_KS 16                    // k per MFMA step
 #define LIN_ROWS 128                 // rows per workgroup
+#ifndef LIN_PF
+#define LIN_PF 4                     // X fragments in flight per lane (k-steps of look-ahead)
+#endif
 
 __device__ __forceinline__ float bf16_to_f32(__bf16 v) {
   return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, v) << 16);
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
   constexpr int N = NT * 32;
   constexpr int PANEL = NT * 3 * 64;                      // bf16x8 fragments per k-step panel
   __shared__ __attribute__((aligned(16))) bf16x8 wbuf[2][PANEL];
+  __shared__ float s_ep[4][N];                            // bias, gamma, beta, dotw: read once, up front
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const i64 row0 = (i64)blockIdx.x * LIN_ROWS + 32 * w;
@@ -82,88 +86,123 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  // prologue: panel 0 -> LDS, X fragment 0 -> registers
+  for (int c = threadIdx.x; c < N; c += OCN_BLOCK) {
+    s_ep[0][c] = bias ? bias[c] : 0.f;
+    s_ep[1][c] = gamma ? gamma[c] : 1.f;
+    s_ep[2][c] = beta ? beta[c] : 0.f;
+    s_ep[3][c] = dotw ? dotw[c] : 0.f;
+  }
+  // prologue: panel 0 -> LDS, the first LIN_PF X fragments -> a register ring
   for (int f = threadIdx.x; f < PANEL; f += OCN_BLOCK) wbuf[0][f] = wp8[f];
-  float4 xa = xrow[0], xb = xrow[1];
+  float4 xr[LIN_PF][2];
+#pragma unroll
+  for (int d = 0; d < LIN_PF; ++d) {
+    const int sd = d < nks ? d : nks - 1;
+    xr[d][0] = xrow[sd * (LIN_KS / 4)];
+    xr[d][1] = xrow[sd * (LIN_KS / 4) + 1];
+  }
   __syncthreads();
 
-  for (int s = 0; s < nks; ++s) {
-    const int cur = s & 1;
-    // next panel and next X fragment in flight while this step computes
-    bf16x8 stage[(PANEL + OCN_BLOCK - 1) / OCN_BLOCK];
-    float4 na = xa, nb = xb;
-    if (s + 1 < nks) {
+  // X streams from HBM exactly once (latency ~1-2 us under load), so its fragments are requested
+  // LIN_PF k-steps ahead; the weight panel comes from L2 and is staged one step ahead.
+#pragma unroll 1
+  for (int s0 = 0; s0 < nks; s0 += LIN_PF) {
 #pragma unroll
-      for (int q = 0; q < (PANEL + OCN_BLOCK - 1) / OCN_BLOCK; ++q) {
-        const int f = threadIdx.x + q * OCN_BLOCK;
-        if (f < PANEL) stage[q] = wp8[(i64)(s + 1) * PANEL + f];
+    for (int d = 0; d < LIN_PF; ++d) {
+      const int s = s0 + d;
+      if (s < nks) {
+        const int cur = s & 1;
+        bf16x8 stage[(PANEL + OCN_BLOCK - 1) / OCN_BLOCK];
+        if (s + 1 < nks) {
+#pragma unroll
+          for (int q = 0; q < (PANEL + OCN_BLOCK - 1) / OCN_BLOCK; ++q) {
+            const int f = threadIdx.x + q * OCN_BLOCK;
+            if (f < PANEL) stage[q] = wp8[(i64)(s + 1) * PANEL + f];
+          }
+        }
+        const float4 xa = xr[d][0], xb = xr[d][1];
+        if (s + LIN_PF < nks) {
+          xr[d][0] = xrow[(s + LIN_PF) * (LIN_KS / 4)];
+          xr[d][1] = xrow[(s + LIN_PF) * (LIN_KS / 4) + 1];
+        }
+        bf16x8 a1, a2, a3;
+        {
+          const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            __bf16 p, q, u;
+            split3(xs[j], p, q, u);
+            a1[j] = p; a2[j] = q; a3[j] = u;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const bf16x8 b1 = wbuf[cur][(t * 3 + 0) * 64 + lane];
+          const bf16x8 b2 = wbuf[cur][(t * 3 + 1) * 64 + lane];
+          const bf16x8 b3 = wbuf[cur][(t * 3 + 2) * 64 + lane];
+          // smallest cross terms first
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+        }
+        if (s + 1 < nks) {
+#pragma unroll
+          for (int q = 0; q < (PANEL + OCN_BLOCK - 1) / OCN_BLOCK; ++q) {
+            const int f = threadIdx.x + q * OCN_BLOCK;
+            if (f < PANEL) wbuf[cur ^ 1][f] = stage[q];
+          }
+        }
+        __syncthreads();
       }
-      na = xrow[(s + 1) * (LIN_KS / 4)];
-      nb = xrow[(s + 1) * (LIN_KS / 4) + 1];
     }
-    bf16x8 a1, a2, a3;
-    {
-      const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        __bf16 p, q, u;
-        split3(xs[j], p, q, u);
-        a1[j] = p; a2[j] = q; a3[j] = u;
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const bf16x8 b1 = wbuf[cur][(t * 3 + 0) * 64 + lane];
-      const bf16x8 b2 = wbuf[cur][(t * 3 + 1) * 64 + lane];
-      const bf16x8 b3 = wbuf[cur][(t * 3 + 2) * 64 + lane];
-      // smallest cross terms first
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
-      acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
-    }
-    if (s + 1 < nks) {
-#pragma unroll
-      for (int q = 0; q < (PANEL + OCN_BLOCK - 1) / OCN_BLOCK; ++q) {
-        const int f = threadIdx.x + q * OCN_BLOCK;
-        if (f < PANEL) wbuf[cur ^ 1][f] = stage[q];
-      }
-    }
-    xa = na; xb = nb;
-    __syncthreads();
   }
 
   // ---- epilogue: lane holds column c = 32t + r of rows (i&3) + 8(i>>2) + 4hh, i = 0..15 ----
   if (bias) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-      const float bv = bias[32 * t + r];
+      const float bv = s_ep[0][32 * t + r];
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] += bv;
     }
   }
   if (gamma) {
-    float g[NT], be[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { g[t] = gamma[32 * t + r]; be[t] = beta[32 * t + r]; }
+    // Row statistics for the 16 rows a lane touches, butterflied together: the 16 independent
+    // shuffles of each step pipeline, where 16 separate 5-step chains would each wait on LDS.
+    float sum[16], sq[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      float sum = 0.f;
+      float a = 0.f;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) sum += acc[t][i];
+      for (int t = 0; t < NT; ++t) a += acc[t][i];
+      sum[i] = a;
+    }
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, OCN_WAVE);
-      const float mean = sum / (float)N;
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sum[i] += __shfl_xor(sum[i], o, OCN_WAVE);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      sum[i] = sum[i] * (1.0f / (float)N);                 // mean (N is a power of two: exact)
       float q = 0.f;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) { const float d = acc[t][i] - mean; q += d * d; }
+      for (int t = 0; t < NT; ++t) { const float d = acc[t][i] - sum[i]; q += d * d; }
+      sq[i] = q;
+    }
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, OCN_WAVE);
-      const float rstd = 1.0f / sqrtf(q / (float)N + eps);
+    for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t][i] = (acc[t][i] - mean) * rstd * g[t] + be[t];
+      for (int i = 0; i < 16; ++i) sq[i] += __shfl_xor(sq[i], o, OCN_WAVE);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sq[i] = rsqrtf(sq[i] * (1.0f / (float)N) + eps);   // rstd, as torch's LayerNorm kernel
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float g = s_ep[1][32 * t + r], be = s_ep[2][32 * t + r];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = (acc[t][i] - sum[i]) * sq[i] * g + be;
     }
   }
   if (relu) {
@@ -176,7 +215,7 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
     // trailing Linear(N -> 1): y[row] = <row, dotw> + dotb, one float per row
     float wv[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wv[t] = dotw[32 * t + r];
+    for (int t = 0; t < NT; ++t) wv[t] = s_ep[3][32 * t + r];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       float d = 0.f;
@@ -189,6 +228,15 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
     }
     return;
   }
+#ifdef OCN_X_LIN_NOSTORE   /* timing experiment: keep the accumulators live, store one word */
+  { float z = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) z += acc[t][i];
+    if (z == 12345.678f) Y[0] = z;
+    return; }
+#endif
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const i64 row = row0 + (i & 3) + 8 * (i >> 2) + 4 * hh;

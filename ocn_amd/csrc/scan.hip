@@ -92,7 +92,55 @@ static int run_scan(Op op, i64 n, i64* out, void* ws, hipStream_t st) {
   return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------
+// processing order of a candidate batch: counting sort of the batch rows by source node (arbitrary
+// order among rows with the same source), so that rows that gather the same neighbourhood are
+// visited back to back
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OCN_BLOCK) void order_count(const i64* __restrict__ node, i64 B,
+                                                         int32_t* __restrict__ counts) {
+  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < B; e += (i64)gridDim.x * blockDim.x)
+    atomicAdd(counts + node[e], 1);
+}
+
+__global__ __launch_bounds__(OCN_BLOCK) void order_scatter(const i64* __restrict__ node, i64 B,
+                                                           unsigned long long* __restrict__ cursor,
+                                                           i64* __restrict__ order) {
+  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < B; e += (i64)gridDim.x * blockDim.x)
+    order[atomicAdd(cursor + node[e], 1ull)] = e;
+}
+
 extern "C" {
+
+int64_t ocn_scan_workspace_bytes(int64_t n);
+
+static inline i64 order_counts_bytes(i64 n_nodes) { return ((n_nodes * 4 + 15) / 16) * 16; }
+
+int64_t ocn_order_workspace_bytes(int64_t n_nodes) {
+  return order_counts_bytes(n_nodes) + (n_nodes + 1) * 8 + ocn_scan_workspace_bytes(n_nodes);
+}
+
+int ocn_order_by_node(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* order, void* workspace,
+                      void* stream) {
+  if (B < 0 || n_nodes <= 0) return OCN_EINVAL;
+  if (B == 0) return 0;
+  if (!node || !order || !workspace) return OCN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* counts = (int32_t*)workspace;
+  i64* offs = (i64*)((char*)workspace + order_counts_bytes(n_nodes));
+  void* scan_ws = (void*)(offs + n_nodes + 1);
+  hipError_t err = hipMemsetAsync(counts, 0, (size_t)n_nodes * 4, st);
+  if (err != hipSuccess) return (int)err;
+  const int grid = grid_for((B + OCN_BLOCK - 1) / OCN_BLOCK, 1024);
+  hipLaunchKernelGGL(order_count, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)node, (i64)B, counts);
+  I32In op{counts};
+  int rc = run_scan(op, (i64)n_nodes, offs, scan_ws, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(order_scatter, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)node, (i64)B,
+                     (unsigned long long*)offs, (i64*)order);
+  return launch_status();
+}
+
 
 int ocn_abi_version(void) { return OCN_ABI_VERSION; }
 

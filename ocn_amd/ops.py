@@ -16,6 +16,7 @@ from ._lib import check, ptr, stream_ptr
 FLAGS_NOSYNC_LIMIT = 1 << 30     # bytes of flag buffer we are willing to over-allocate to avoid a host sync
 validate_indices = True          # bounds-check candidate edges on the host side (one sync per batch)
 stage_timer = None               # optional object with .mark(name): bench.py records HIP events between stages
+sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 
 
 def _mark(name: str) -> None:
@@ -86,7 +87,7 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
              walk: bool = False):
     """Intersection pass.  ``walk=False``: flags of N(src) against the rows of dst in t1 (and t2).
     ``walk=True``: the pygho route on A itself (t1/t2 ignored): cn1 flags + walk counts.
-    Returns (off, flags, wc|None, hist[N,2] int64 packed, cnt1, cnt2|None, status)."""
+    Returns (order|None, off, flags, wc|None, hist[N,2] int64 packed, cnt1, cnt2|None, status)."""
     dev = src.device
     B = src.numel()
     _req(rowptrA, torch.int64, "rowptrA", 1); _req(colA, torch.int32, "colA", 1)
@@ -100,6 +101,15 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     if B > MAX_BATCH:
         raise ValueError(f"candidate batch of {B} edges exceeds the histogram field width ({MAX_BATCH})")
     _mark("begin")
+    # processing order: candidates with the same / nearby source node share most of the rows they
+    # gather, so visiting them together turns HBM row fetches into L2 hits (outputs stay in batch order)
+    order = None
+    if B >= sort_edges_min_batch:
+        order = torch.empty(B, dtype=torch.int64, device=dev)
+        n_src = rowptrA.numel() - 1
+        ows = torch.empty(int(_lib.lib().ocn_order_workspace_bytes(n_src)) // 8 + 1, dtype=torch.int64, device=dev)
+        check(_lib.lib().ocn_order_by_node(ptr(src), B, n_src, ptr(order), ptr(ows), stream_ptr()),
+              "ocn_order_by_node")
     off = edge_offsets(rowptrA, src)
     bound = B * max(int(max_deg_a), 0)
     cap = bound if bound <= FLAGS_NOSYNC_LIMIT else int(off[-1].item())
@@ -111,16 +121,16 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     _mark("cn_prep")
     if walk:
-        check(_lib.lib().ocn_cn_walk_flags(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), B, ptr(off), ptr(flags),
+        check(_lib.lib().ocn_cn_walk_flags(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags),
                                            ptr(wc), cap, ptr(hist), ptr(cnt1), ptr(cnt2), ptr(status),
                                            stream_ptr()), "ocn_cn_walk_flags")
     else:
         check(_lib.lib().ocn_cn_flags(ptr(rowptrA), ptr(colA), ptr(t1[0]), ptr(t1[1]),
                                       ptr(t2[0] if t2 else None), ptr(t2[1] if t2 else None),
-                                      ptr(src), ptr(dst), B, ptr(off), ptr(flags), cap, ptr(hist),
+                                      ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags), cap, ptr(hist),
                                       ptr(cnt1), ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_flags")
     _mark("cn_flags")
-    return off, flags, wc, hist, cnt1, cnt2, status
+    return order, off, flags, wc, hist, cnt1, cnt2, status
 
 
 def cn_weights_cn5(hist: Tensor, innerprod: Tensor, valued: bool = False) -> Tensor:
@@ -142,14 +152,15 @@ def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
     return hist.view(torch.float32)
 
 
-def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights: Tensor, h: Tensor):
+def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights: Tensor, h: Tensor,
+              order: Optional[Tensor] = None):
     _req(weights, torch.float32, "weights", 2)
     _req(h, torch.float32, "h", 2)
     if weights.shape[0] != h.shape[0] or weights.shape[1] != 4:
         raise ValueError("weights must be [N,4] with N = h.shape[0]")
     B, H = src.numel(), h.shape[1]
     out = torch.empty(3, B, H, dtype=torch.float32, device=h.device)
-    check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), B, ptr(off), ptr(flags),
+    check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags),
                                    ptr(wc), ptr(weights), ptr(h), H, ptr(out[0]), ptr(out[1]), ptr(out[2]),
                                    stream_ptr()), "ocn_cn_gather")
     _mark("cn_gather")
@@ -278,6 +289,7 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln=None, re
     M, K = x.shape
     N = weight.shape[0]
     panel = linear_panel(weight)
+    _mark("mlp_glue")
     y = torch.empty((M, 1) if dot is not None else (M, N), dtype=torch.float32, device=x.device)
     g = b = None
     eps = 0.0
@@ -289,4 +301,5 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln=None, re
         dw = dw.reshape(-1)
     check(_lib.lib().ocn_linear_bf16x6(ptr(x), M, K, ptr(panel), N, ptr(bias), ptr(g), ptr(b), float(eps),
                                        int(relu), ptr(dw), ptr(db), ptr(y), stream_ptr()), "ocn_linear_bf16x6")
+    _mark("linear")
     return y

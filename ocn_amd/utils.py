@@ -63,7 +63,7 @@ class CNState:
         self.B = self.src.numel()
         self.N = adj.size(1)
         ops.check_edges(self.src, self.dst, adj.size(0), adj.size(0) if walk else t1.size(0))
-        self.off, self.flags, self.wc, self.hist, self.cnt1, self.cnt2, self.status = ops.cn_flags(
+        (self.order, self.off, self.flags, self.wc, self.hist, self.cnt1, self.cnt2, self.status) = ops.cn_flags(
             adj._rowptr, adj._col, None if walk else (t1._rowptr, t1._col),
             None if (walk or t2 is None) else (t2._rowptr, t2._col), self.src, self.dst, self.N,
             adj.max_rowcount(), walk=walk)
@@ -90,7 +90,7 @@ class CNState:
 
     def gather(self, weights: Tensor, h: Tensor):
         return ops.cn_gather(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off,
-                             self.flags, self.wc, weights, h)
+                             self.flags, self.wc, weights, h, order=self.order)
 
     def materialize(self, bit: int) -> SparseTensor:
         """[B, N] matrix of the entries whose flag has ``bit`` set; values 1.0, or the walk counts

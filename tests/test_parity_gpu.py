@@ -425,3 +425,15 @@ def test_linear_bf16x6(hiplib, M, K, N):
         lin.weight.mul_(2.0)                                                          # in-place update -> panel rebuilt
         assert torch.allclose(ops.linear(x, lin.weight, lin.bias), torch.nn.functional.linear(x, lin.weight, lin.bias),
                               atol=4e-6 * scale, rtol=1e-5)
+
+
+def test_processing_order_is_a_permutation_grouped_by_source(hiplib):
+    from ocn_amd import ops
+    n, B = 100000, 50000
+    src = torch.randint(0, n, (B,), device=DEV)
+    order = torch.empty(B, dtype=torch.int64, device=DEV)
+    ws = torch.empty(int(hiplib.ocn_order_workspace_bytes(n)) // 8 + 1, dtype=torch.int64, device=DEV)
+    ops.check(hiplib.ocn_order_by_node(ops.ptr(src), B, n, ops.ptr(order), ops.ptr(ws), ops.stream_ptr()), "order")
+    assert torch.equal(torch.sort(order).values, torch.arange(B, device=DEV))
+    s = src[order]
+    assert bool((s[1:] >= s[:-1]).all())

@@ -31,6 +31,17 @@ def child():
     adj, adj2, h, e = wl["adj"], wl["adj2"], wl["h"], wl["edges"]
     ops.validate_indices = False
     iters = int(os.environ.get("KB_ITERS", "20"))
+    mode = os.environ.get("KB_SORT", "")
+    if mode == "src":
+        e = e[:, torch.argsort(e[0])].contiguous()
+    elif mode == "src_xcd":       # sorted by src, then dealt so that blocks b, b+8, b+16.. (one XCD) get a contiguous run
+        o = torch.argsort(e[0])
+        nb = e.shape[1]
+        b = torch.arange(nb, device=dev)
+        pos = (b % 8) * (nb // 8) + b // 8
+        e = e[:, o[pos]].contiguous()
+    elif mode == "dst":
+        e = e[:, torch.argsort(e[1])].contiguous()
 
     def timed(fn):
         fn()
