@@ -36,6 +36,16 @@ __device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& 
   p3 = (__bf16)r2;
 }
 
+__device__ __forceinline__ void split_frag(const float4& xa, const float4& xb, bf16x8& a1, bf16x8& a2, bf16x8& a3) {
+  const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    __bf16 p, q, u;
+    split3(xs[j], p, q, u);
+    a1[j] = p; a2[j] = q; a3[j] = u;
+  }
+}
+
 // Wp[s][t][split][lane][8]: the B fragment (k = 16s + 8(lane>>5) + j, n = 32t + (lane&31)) of
 // split `split`, so that one k-step's panel is a contiguous, lane-linear LDS image.
 __global__ __launch_bounds__(OCN_BLOCK) void split_weight_kernel(const float* __restrict__ W, int N, int K,
@@ -104,7 +114,11 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
   __syncthreads();
 
   // X streams from HBM exactly once (latency ~1-2 us under load), so its fragments are requested
-  // LIN_PF k-steps ahead; the weight panel comes from L2 and is staged one step ahead.
+  // LIN_PF k-steps ahead; the weight panel comes from L2 and is staged one step ahead.  The bf16
+  // split of step s+1's fragment is issued in the shadow of step s's MFMAs (VALU and MFMA pipes
+  // run side by side); done at the top of the step it would idle the matrix pipe ~25 % of the time.
+  bf16x8 a1, a2, a3;
+  split_frag(xr[0][0], xr[0][1], a1, a2, a3);
 #pragma unroll 1
   for (int s0 = 0; s0 < nks; s0 += LIN_PF) {
 #pragma unroll
@@ -113,6 +127,7 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
       if (s < nks) {
         const int cur = s & 1;
         bf16x8 stage[(PANEL + OCN_BLOCK - 1) / OCN_BLOCK];
+#ifndef OCN_X_LIN_NOW    /* timing experiments: no weight-panel reload / no X reload */
         if (s + 1 < nks) {
 #pragma unroll
           for (int q = 0; q < (PANEL + OCN_BLOCK - 1) / OCN_BLOCK; ++q) {
@@ -120,26 +135,26 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
             if (f < PANEL) stage[q] = wp8[(i64)(s + 1) * PANEL + f];
           }
         }
-        const float4 xa = xr[d][0], xb = xr[d][1];
-        if (s + LIN_PF < nks) {
+#endif
+#ifndef OCN_X_LIN_NOX
+        if (s + LIN_PF < nks) {                            // slot d was consumed when step s was split
           xr[d][0] = xrow[(s + LIN_PF) * (LIN_KS / 4)];
           xr[d][1] = xrow[(s + LIN_PF) * (LIN_KS / 4) + 1];
         }
-        bf16x8 a1, a2, a3;
-        {
-          const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#endif
+        bf16x8 n1 = a1, n2 = a2, n3 = a3;
+        // B fragments are fetched from LDS one column tile ahead of the MFMAs that consume them
+        bf16x8 bq[2][3];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            __bf16 p, q, u;
-            split3(xs[j], p, q, u);
-            a1[j] = p; a2[j] = q; a3[j] = u;
-          }
-        }
+        for (int u = 0; u < 3; ++u) bq[0][u] = wbuf[cur][u * 64 + lane];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-          const bf16x8 b1 = wbuf[cur][(t * 3 + 0) * 64 + lane];
-          const bf16x8 b2 = wbuf[cur][(t * 3 + 1) * 64 + lane];
-          const bf16x8 b3 = wbuf[cur][(t * 3 + 2) * 64 + lane];
+          if (t + 1 < NT) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) bq[(t + 1) & 1][u] = wbuf[cur][((t + 1) * 3 + u) * 64 + lane];
+          }
+          __builtin_amdgcn_sched_barrier(0);               // keep the next tile's LDS reads ahead of these MFMAs
+          const bf16x8 b1 = bq[t & 1][0], b2 = bq[t & 1][1], b3 = bq[t & 1][2];
           // smallest cross terms first
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
@@ -147,7 +162,13 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);
+          if (t == 0 && s + 1 < nks) {
+            const int dn = (d + 1) % LIN_PF;
+            split_frag(xr[dn][0], xr[dn][1], n1, n2, n3);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
+#ifndef OCN_X_LIN_NOW
         if (s + 1 < nks) {
 #pragma unroll
           for (int q = 0; q < (PANEL + OCN_BLOCK - 1) / OCN_BLOCK; ++q) {
@@ -155,7 +176,11 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
             if (f < PANEL) wbuf[cur ^ 1][f] = stage[q];
           }
         }
+#endif
+        a1 = n1; a2 = n2; a3 = n3;
+#ifndef OCN_X_LIN_NOBAR
         __syncthreads();
+#endif
       }
     }
   }
