@@ -107,7 +107,8 @@ def cpu_baseline(wl, args):
     """The oracle (a port of the reference's op sequence, torch CPU ops, all host cores) on a bounded
     sample: the first ``b`` edges of the batch as a batch of their own."""
     from oracle import ocn_oracle as O
-    torch.set_num_threads(os.cpu_count())
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
+    torch.set_num_threads(ncores)
     adj, adj2 = wl["adj"], wl["adj2"]
     r, c, _ = adj.coo()
     r2, c2, _ = adj2.coo()
@@ -129,9 +130,24 @@ def cpu_baseline(wl, args):
     while t < 6.0 and b * 2 <= wl["edges"].shape[1] and b < 16384:
         b *= 2
         t, out = run(b)
-    return dict(value=b / t, unit="edges/s", cores=os.cpu_count(), kind="port",
+    return dict(value=b / t, unit="edges/s", cores=ncores, kind="port",
                 sample=f"first {b} edges of the step's batch as one batch, oracle/ocn_oracle.py "
                        f"adjoverlap x2 + cn5_forward, {t:.2f} s, torch {torch.get_num_threads()} threads"), b, out
+
+
+def pmc_traffic(kernel_substr):
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r*_pmc.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  FETCH_SIZE is
+    doubled (gfx950 counts 128-B requests as 64 B — MI355X_MICROARCH.md §HBM; calibrated on
+    rows_ln_relu / combine3 whose byte counts are known exactly), both are in KiB."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    if not files:
+        return None
+    for k, v in json.load(open(files[-1])).items():
+        if kernel_substr in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            return (2.0 * v["FETCH_SIZE"]["avg"] + v["WRITE_SIZE"]["avg"]) * 1024.0
+    return None
 
 
 def main():
@@ -223,14 +239,16 @@ def main():
             g = "cn_gather"
             roof_hbm = dict(bound="hbm", kernel="cn_gather_kernel", achieved=ab[g] / (stages[g]["ms"] * 1e-3) / 1e9,
                             peak=HBM_PEAK / 1e9, unit="GB/s", frac=ab[g] / (stages[g]["ms"] * 1e-3) / HBM_PEAK,
-                            traffic=None, algorithmic_bytes_per_launch=ab[g], avg_launch_ms=stages[g]["ms"],
+                            traffic=pmc_traffic("cn_gather_kernel"), algorithmic_bytes_per_launch=ab[g],
+                            avg_launch_ms=stages[g]["ms"],
                             note="algorithmic bytes price one embedding row per CN entry; rows shared by "
                                  "candidates processed together are served by L2, so frac can exceed 1")
             if dom == "linear":
                 fl = 2.0 * mine.shape[1] * H * H          # one Linear(H,H) over the batch
                 t = stages["linear"]["ms"] * 1e-3
                 roof = dict(bound="mfma", kernel="linear_bf16x6_kernel", achieved=fl / t / 1e12,
-                            peak=F32_MFMA_PEAK / 1e12, unit="TFLOP/s", frac=fl / t / F32_MFMA_PEAK, traffic=None,
+                            peak=F32_MFMA_PEAK / 1e12, unit="TFLOP/s", frac=fl / t / F32_MFMA_PEAK,
+                            traffic=pmc_traffic("linear_bf16x6_kernel"),
                             algorithmic_flops_per_launch=fl, avg_launch_ms=stages["linear"]["ms"],
                             launches_per_step=stages["linear"]["launches"] / args.steps,
                             executed_bf16_tflops=6 * fl / t / 1e12, executed_frac_of_bf16_peak=6 * fl / t / BF16_MFMA_PEAK,
