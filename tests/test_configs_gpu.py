@@ -1,0 +1,118 @@
+"""End-to-end parity of the five BASELINE.json configurations (encoder -> CN builder -> predictor)
+against the oracle, at sizes the oracle finishes in seconds: Cora and ddi at their full graph size,
+collab / ppa / citation2 on scaled-down graphs of the same shape (the full collab shape is covered by
+the property test in test_parity_gpu.py and by bench.py's live oracle check)."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from oracle import ocn_oracle as O
+from ocn_amd.synth import dataset_like, sample_edges
+from tests.helpers import close
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _graph(name, scale, seed=0):
+    ei, n, shape = dataset_like(name, seed=seed, scale=scale)
+    oadj = O.to_symmetric(O.from_edge_index(ei, n))
+    from ocn_amd.sparse import SparseTensor
+    adj = SparseTensor.from_edge_index(ei.to(DEV), sparse_sizes=(n, n)).to_symmetric()
+    assert adj.nnz() == oadj.nnz
+    return n, shape, oadj, adj
+
+
+def _sd(m):
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+# name, scale, encoder class, conv, layers, H, predictor, route, B, ln, res, jk, use ids, sum
+CONFIGS = [
+    ("cora", 1.0, "GCN", "puregcn", 1, 256, "cn5", "adj2", 1152, True, False, True, False, 0.0),      # README.md:27
+    ("collab", 0.05, "GCN", "gin", 1, 256, "cn5", "adj2", 4096, True, False, True, False, 0.0),      # README.md:42
+    ("ppa", 0.01, "GCN2", "gcn", 1, 64, "cn5", "walk", 2048, True, False, True, True, 0.0),          # README.md:47
+    ("citation2", 0.002, "GCN3", "gcn", 5, 32, "cn7", "walk", 2048, True, True, True, False, 1.0),   # README.md:92
+    ("ddi", 1.0, "GCN", "puregcn", 3, 64, "cn7", "block", 512, False, True, False, True, 2.74),      # README.md:98
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"{c[0]}-{c[6]}-{c[7]}")
+def test_baseline_config_end_to_end(hiplib, cfg):
+    import ocn_amd.model as M
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import adjoverlap, get_cn1_cn2, sparse_tensor_multiply
+    name, scale, enc_cls, conv, L, H, pname, route, B, ln, res, jk, ids, sum_fill = cfg
+    n, shape, oadj, adj = _graph(name, scale)
+    torch.manual_seed(1)
+    max_x = n if ids else -1
+    fin = H if ids else (shape["feat"] or H)
+    x = torch.arange(n) if ids else torch.randn(n, fin)
+    enc = getattr(M, enc_cls)(fin, H, H, L, 0.1, ln, res, max_x, conv, jk, 0.0, xdropout=0.3, taildropout=0.2).eval()
+    pred = M.predictor_dict[pname](H, H, 1, 3, 0.05, 0.1, True, use_xlin=True, tailact=True, beta=0.33).eval()
+    args = SimpleNamespace(sum=sum_fill, adj2byblock=route == "block")
+    e = sample_edges(oadj.row, oadj.col, n, B, seed=3)
+
+    # oracle
+    variant = {"GCN": 1, "GCN2": 2, "GCN3": 3}[enc_cls]
+    h_ref = O.gcn_forward(_sd(enc), x, oadj, num_layers=L, conv_fn=conv, ln=ln, res=res, jk=jk, max_x=max_x,
+                          variant=variant)
+    if route == "walk":
+        c1, c2 = O.get_cn1_cn2(oadj, e)
+    else:
+        oadj2 = O.adj2_by_block(oadj, 1024) if route == "block" else O.adj2_sparse(oadj)
+        c1, c2 = O.adjoverlap(oadj, oadj, e), O.adjoverlap(oadj, oadj2, e)
+    fwd = O.cn5_forward if pname == "cn5" else (lambda *a, **k: O.cn7_forward(*a[:5], sum_fill, *a[5:], **k))
+    ref = fwd(_sd(pred), h_ref, c1, c2, e, True, True)
+
+    # product, written the way the reference drivers call it
+    with torch.no_grad():
+        h = enc.to(DEV)(x.to(DEV), adj)
+        assert close(h, h_ref, atol=2e-5, rtol=2e-5), (h.cpu() - h_ref).abs().max()
+        ed = e.to(DEV)
+        if route == "walk":
+            cn1, cn2 = get_cn1_cn2(adj, ed)
+        else:
+            if route == "block":
+                adj2 = sparse_tensor_multiply(adj, 1024)
+            else:
+                sp = adj.to_torch_sparse_coo_tensor()
+                adj2 = SparseTensor.from_torch_sparse_coo_tensor(sp @ sp, False)
+            assert adj2.nnz() == oadj2.nnz
+            cn1, cn2 = adjoverlap(adj, adj, ed), adjoverlap(adj, adj2, ed)
+        assert cn1.counts().cpu().tolist() == torch.bincount(c1.row, minlength=B).tolist()
+        assert cn2.counts().cpu().tolist() == torch.bincount(c2.row, minlength=B).tolist()
+        out = pred.to(DEV)(h, adj, cn1, cn2, ed, args)
+    # the encoder's own 2e-5 slack feeds the heads: allow it once more on the scores
+    assert out.shape == (B, 1)
+    assert close(out, ref, atol=3e-5, rtol=3e-5), (out.cpu() - ref).abs().max()
+    # and with the SAME embeddings, the predictor alone is within the 1e-5 bar
+    with torch.no_grad():
+        if route == "walk":
+            cn1, cn2 = get_cn1_cn2(adj, ed)
+        else:
+            cn1, cn2 = adjoverlap(adj, adj, ed), adjoverlap(adj, adj2, ed)
+        out2 = pred(h_ref.to(DEV), adj, cn1, cn2, ed, args)
+    assert close(out2, ref), (out2.cpu() - ref).abs().max()
+
+
+def test_score_edges_equals_the_drivers_batch_loop(hiplib):
+    """pipeline.score_edges == torch.cat([predictor(...) for perm in PermIterator(.., False)])."""
+    import ocn_amd.model as M
+    from ocn_amd.pipeline import score_edges
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import PermIterator, adjoverlap
+    n, shape, oadj, adj = _graph("collab", 0.02)
+    sp = adj.to_torch_sparse_coo_tensor()
+    adj2 = SparseTensor.from_torch_sparse_coo_tensor(sp @ sp, False)
+    H = 64
+    torch.manual_seed(2)
+    h = torch.randn(n, H, device=DEV)
+    pred = M.predictor_dict["cn5"](H, H, 1, 3, 0.0, 0.0, True).to(DEV).eval()
+    edges = sample_edges(oadj.row, oadj.col, n, 5000, seed=9).t().contiguous().to(DEV)       # [n, 2] like split_edge
+    with torch.no_grad():
+        loop = torch.cat([pred(h, adj, adjoverlap(adj, adj, edges[perm].t()), adjoverlap(adj, adj2, edges[perm].t()),
+                               edges[perm].t()).squeeze() for perm in PermIterator(DEV, edges.shape[0], 2048, False)])
+    got = score_edges(pred, h, adj, adj2, edges, 2048)
+    assert got.shape == (5000,) and torch.equal(got, loop)
