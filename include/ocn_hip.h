@@ -109,6 +109,18 @@ int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA,
                   const float* weights /* [N][4] */, const float* h, int32_t H,
                   float* xcn1, float* xcn2, float* xij, void* stream);
 
+/* Backward of the pooling with respect to h (training drop-in): for upstream
+ * gradients g1, g2, g3 of xcn1, xcn2, xij ([B][H] each),
+ *   dh[k] += w1[k] g1[e] + w2(e,k) g2[e]  over the CN entries (the transposed spmm_add),
+ *   dh[i] += g3[e] (.) h[j],  dh[j] += g3[e] (.) h[i].
+ * dh [N][H] must be initialised by the caller (zeros); fp32 atomic adds (summation order varies
+ * between runs).  H in {16..512, power of two}. */
+int ocn_cn_gather_backward(const int64_t* rowptrA, const int32_t* colA,
+                           const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
+                           const int64_t* off, const uint8_t* flags, const int32_t* wc,
+                           const float* weights, const float* h, int32_t H,
+                           const float* g1, const float* g2, const float* g3, float* dh, void* stream);
+
 /* CSR SpMM of the encoders: torch_sparse spmm_add/mean/max (model.py:42-55), PyG GCNConv
  * propagate (model.py:58-68), pygho/torch COO @ dense (model.py:105-113).
  *   y[r] = post[r] * reduce_k( pre[r]^a * pre[k] * x[k] )  (+ self term)

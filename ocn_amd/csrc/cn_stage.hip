@@ -433,6 +433,74 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_generic(
 }
 
 // ---------------------------------------------------------------------------------------------
+// K3 backward: dh[k] += wa·g1[e] + wb·g2[e] over the flagged neighbours (the transposed pooling),
+// dh[i] += g3[e] ⊙ h[j], dh[j] += g3[e] ⊙ h[i].  fp32 atomics, one 1-KiB row segment per
+// wave-instruction (the shape the memory-side atomic units take at full rate).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void atomic_add4(float* p, const float4& v) {
+  atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+
+template <int LPE, int NV>
+__global__ __launch_bounds__(OCN_BLOCK) void cn_scatter_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
+    const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
+    const float4* __restrict__ weights, const float* __restrict__ h, int H,
+    const float* __restrict__ g1, const float* __restrict__ g2, const float* __restrict__ g3,
+    float* __restrict__ dh) {
+  constexpr int GPW = OCN_WAVE / LPE;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane % LPE;
+  const int gbase = lane - gl;
+  const i64 slot = ((i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
+  if (slot >= B) return;
+  const i64 e = order ? order[slot] : slot;
+  const i64 i = src[e], j = dst[e];
+  const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+  const i64 base = off[e];
+  const i64 rowq = H >> 2;
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  float4 v1[NV], v2[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    v1[v] = reinterpret_cast<const float4*>(g1)[e * rowq + gl + v * LPE];
+    v2[v] = reinterpret_cast<const float4*>(g2)[e * rowq + gl + v * LPE];
+  }
+  for (i64 p0 = 0; p0 < da; p0 += LPE) {
+    const i64 p = p0 + gl;
+    int32_t k = 0;
+    unsigned f = 0;
+    if (p < da) { k = colA[a0 + p]; f = flags[base + p]; }
+    float wa = 0.f, wb = 0.f;
+    if (f) entry_weights(f, weights[k], wc ? (float)wc[base + p] : 1.0f, wa, wb);
+    unsigned long long m = __ballot((wa != 0.f) | (wb != 0.f));
+    if (LPE < 64) m = (m >> gbase) & ((1ull << (LPE & 63)) - 1ull);
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int32_t kk = __shfl(k, gbase + b, OCN_WAVE);
+      const float a = __shfl(wa, gbase + b, OCN_WAVE), bb = __shfl(wb, gbase + b, OCN_WAVE);
+      float* row = dh + (i64)kk * H + 4 * gl;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float4 c;
+        c.x = a * v1[v].x + bb * v2[v].x; c.y = a * v1[v].y + bb * v2[v].y;
+        c.z = a * v1[v].z + bb * v2[v].z; c.w = a * v1[v].w + bb * v2[v].w;
+        atomic_add4(row + 4 * v * LPE, c);
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const float4 g = reinterpret_cast<const float4*>(g3)[e * rowq + gl + v * LPE];
+    const float4 hi = h4[i * rowq + gl + v * LPE], hj = h4[j * rowq + gl + v * LPE];
+    atomic_add4(dh + i * H + 4 * (gl + v * LPE), make_float4(g.x * hj.x, g.y * hj.y, g.z * hj.z, g.w * hj.w));
+    atomic_add4(dh + j * H + 4 * (gl + v * LPE), make_float4(g.x * hi.x, g.y * hi.y, g.z * hi.z, g.w * hi.w));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
 extern "C" {
@@ -526,6 +594,35 @@ int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* sr
     default:
       hipLaunchKernelGGL(cn_gather_generic, dim3((unsigned)((B + OCN_WPB - 1) / OCN_WPB)),
                          dim3(OCN_BLOCK), 0, st, GATHER_ARGS);
+  }
+  return launch_status();
+}
+
+#define SCATTER_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, \
+                     (const i64*)off, flags, wc, (const float4*)weights, h, (int)H, g1, g2, g3, dh
+#define LAUNCH_SCATTER(LPE, NV)                                                                     \
+  do {                                                                                              \
+    const i64 epb = (i64)OCN_WPB * (OCN_WAVE / (LPE));                                              \
+    hipLaunchKernelGGL((cn_scatter_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)),         \
+                       dim3(OCN_BLOCK), 0, (hipStream_t)stream, SCATTER_ARGS);                      \
+  } while (0)
+
+int ocn_cn_gather_backward(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
+                           const int64_t* dst, const int64_t* order, int64_t B, const int64_t* off,
+                           const uint8_t* flags, const int32_t* wc, const float* weights,
+                           const float* h, int32_t H, const float* g1, const float* g2,
+                           const float* g3, float* dh, void* stream) {
+  if (B < 0 || H <= 0) return OCN_EINVAL;
+  if (B == 0) return 0;
+  if (!rowptrA || !src || !dst || !off || !weights || !h || !g1 || !g2 || !g3 || !dh) return OCN_EINVAL;
+  switch (H) {
+    case 16:  LAUNCH_SCATTER(4, 1); break;
+    case 32:  LAUNCH_SCATTER(8, 1); break;
+    case 64:  LAUNCH_SCATTER(16, 1); break;
+    case 128: LAUNCH_SCATTER(32, 1); break;
+    case 256: LAUNCH_SCATTER(64, 1); break;
+    case 512: LAUNCH_SCATTER(64, 2); break;
+    default: return OCN_EINVAL;
   }
   return launch_status();
 }

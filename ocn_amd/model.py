@@ -59,6 +59,56 @@ class DropAdj(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------
+# autograd glue (training drop-in): the HIP kernels are linear in x / h, their transposes are HIP
+# kernels too
+# ------------------------------------------------------------------------------------------
+class _SpmmFn(torch.autograd.Function):
+    """y = M x for one of the encoder operators.  The drivers' adjacencies are symmetric
+    (``to_symmetric``, NeighborOverlap_large.py:63, ogbdataset.py:45), and so are A, P(A+I)P and
+    D^-½(A+I)D^-½: the backward is the same kernel applied to the gradient.  ``mean`` (D⁻¹A) has the
+    transpose A D⁻¹; ``max`` is not differentiated here."""
+
+    @staticmethod
+    def forward(ctx, x, adj, kw):
+        ctx.adj, ctx.kw = adj, kw
+        return ops.spmm_csr(adj._rowptr, adj._col, x, **kw)
+
+    @staticmethod
+    def backward(ctx, g):
+        adj, kw = ctx.adj, dict(ctx.kw)
+        g = g.contiguous()
+        mode = kw.get("mode", "sum")
+        if mode == "max":
+            raise NotImplementedError("backward of max aggregation")
+        if mode == "mean":
+            deg = (adj._rowptr[1:] - adj._rowptr[:-1]).clamp(min=1).to(torch.float32)
+            return ops.spmm_csr(adj._rowptr, adj._col, g, pre=1.0 / deg, mode="sum"), None, None
+        return ops.spmm_csr(adj._rowptr, adj._col, g, **kw), None, None
+
+
+def _spmm(adj: SparseTensor, x: Tensor, **kw) -> Tensor:
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _SpmmFn.apply(x, adj, kw)
+    return ops.spmm_csr(adj._rowptr, adj._col, x, **kw)
+
+
+class _PoolFn(torch.autograd.Function):
+    """(xcn1, xcn2, x_i ⊙ x_j) = pooling(h): linear in h except for the Hadamard term; the column
+    weights depend on the graph and the batch only."""
+
+    @staticmethod
+    def forward(ctx, h, st, w):
+        ctx.st = st
+        ctx.save_for_backward(h, w)
+        return st.gather(w, h)
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3):
+        h, w = ctx.saved_tensors
+        return ctx.st.gather_backward(w, h, g1, g2, g3), None, None
+
+
+# ------------------------------------------------------------------------------------------
 # message passing layers
 # ------------------------------------------------------------------------------------------
 def _no_values(adj: SparseTensor, who: str) -> None:
@@ -83,11 +133,10 @@ class PureConv(nn.Module):
         x = self.lin(x).contiguous()
         _no_values(adj_t, "PureConv")
         if self.aggr in ("mean", "max", "sum"):
-            return ops.spmm_csr(adj_t._rowptr, adj_t._col, x, mode=self.aggr)
+            return _spmm(adj_t, x, mode=self.aggr)
         if self.aggr == "gcn":
             norm = ops.deg_rsqrt(adj_t._rowptr, 1.0)
-            return ops.spmm_csr(adj_t._rowptr, adj_t._col, x, pre=norm, post=norm, mode="sum",
-                                edge_scale=False, self_mode=1)
+            return _spmm(adj_t, x, pre=norm, post=norm, mode="sum", edge_scale=False, self_mode=1)
         raise ValueError(self.aggr)
 
 
@@ -111,10 +160,10 @@ class GCNConv(nn.Module):
         x = self.lin(x).contiguous()
         if self.normalize:
             dinv = ops.deg_rsqrt(adj_t._rowptr, 1.0)        # degree of A + I (A has no self loops)
-            out = ops.spmm_csr(adj_t._rowptr, adj_t._col, x, pre=dinv, mode="sum", edge_scale=True,
-                               self_mode=2 if self.add_self_loops else 0)
+            out = _spmm(adj_t, x, pre=dinv, mode="sum", edge_scale=True,
+                        self_mode=2 if self.add_self_loops else 0)
         else:
-            out = ops.spmm_csr(adj_t._rowptr, adj_t._col, x, mode=self.aggr)
+            out = _spmm(adj_t, x, mode=self.aggr)
         return out if self.bias is None else out + self.bias
 
 
@@ -152,10 +201,10 @@ class PureConv2(nn.Module):
         _no_values(adj_t, "PureConv2")
         x = x.contiguous()
         if self.aggr in ("mean", "max", "sum"):
-            x = ops.spmm_csr(adj_t._rowptr, adj_t._col, x, mode=self.aggr)
+            x = _spmm(adj_t, x, mode=self.aggr)
         elif self.aggr == "gcn":
             norm = ops.deg_rsqrt(adj_t._rowptr, 1.0)
-            x = ops.spmm_csr(adj_t._rowptr, adj_t._col, x, pre=norm, mode="sum", edge_scale=True)
+            x = _spmm(adj_t, x, pre=norm, mode="sum", edge_scale=True)
         return self.lin(x)
 
 
@@ -360,21 +409,34 @@ class _CNPredictorBase(nn.Module):
             ops._mark("allreduce_hist")
         return st
 
-    def _no_backward(self, x: Tensor) -> None:
-        if torch.is_grad_enabled() and (x.requires_grad or self.training):
-            raise NotImplementedError(
-                "ocn_amd predictors are forward-only this round: call under torch.no_grad() / .eval() "
-                "(autograd for the fused pooling is the next scope row, SURVEY.md §8f-1)")
+    def _pool(self, st, w, x):
+        x = x.contiguous()
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _PoolFn.apply(x, st, w)
+        return st.gather(w, x)
+
+    def innerprod1(self, st):
+        """model.py:2241-2250: in training the running mean of Σ(cn2 ⊙ ncn1) is updated and used;
+        in eval the stored buffer is used as is."""
+        if self.training:
+            with torch.no_grad():
+                ip = st.cn5_batch_innerprod()
+                self.n += 1
+                beta = self.n ** -1
+                self.innerprod *= (1 - beta)
+                self.innerprod += beta * ip
+        return self.innerprod
 
     def _heads(self, x, xcn1, xcn2, xij):
         alpha = torch.sigmoid(self.alpha).cumprod(-1)
-        if self.training or not xij.is_cuda or xij.shape[-1] % 4:
+        if self.training or torch.is_grad_enabled() or not xij.is_cuda or xij.shape[-1] % 4:
             xij = self.xijlin(xij)
             xcn1 = self.xcn1lin(xcn1)
             xcn2 = self.xcn2lin(xcn2)
             return self.lin(alpha[0] * xcn1 + alpha[1] * xcn2 + self.beta * xij)
-        # eval: same modules, same parameters; LayerNorm+ReLU and the branch mix run as one HIP
-        # pass each instead of separate elementwise kernels.  The Linear layers stay library GEMMs.
+        # eval under no_grad (the drivers' test()): same modules, same parameters, walked by
+        # _seq_eval onto the bf16x6 MFMA Linear kernel with fused LayerNorm/ReLU epilogues.  With
+        # autograd on, the torch modules above run instead so that the graph is recorded.
         xij = _seq_eval(self.xijlin, xij)
         xcn1 = _seq_eval(self.xcn1lin, xcn1)
         xcn2 = _seq_eval(self.xcn2lin, xcn2)
@@ -388,10 +450,9 @@ class CNLinkPredictorOringin(_CNPredictorBase):
 
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
-        self._no_backward(x)
         st = self._exchange(fuse(cn1, cn2, tar_ei))
-        w = st.weights_cn5(self.innerprod)
-        xcn1, xcn2, xij = st.gather(w, x.contiguous())
+        w = st.weights_cn5(self.innerprod1(st))
+        xcn1, xcn2, xij = self._pool(st, w, x)
         return self._heads(x, xcn1, xcn2, xij)
 
     def forward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False):
@@ -404,10 +465,9 @@ class CNLinkPredictorbaselearn(_CNPredictorBase):
 
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, args, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
-        self._no_backward(x)
         st = self._exchange(fuse(cn1, cn2, tar_ei))
         w = st.weights_cn7(float(args.sum))
-        xcn1, xcn2, xij = st.gather(w, x.contiguous())
+        xcn1, xcn2, xij = self._pool(st, w, x)
         return self._heads(x, xcn1, xcn2, xij)
 
     def forward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False):

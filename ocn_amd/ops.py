@@ -16,6 +16,7 @@ from ._lib import check, ptr, stream_ptr
 FLAGS_NOSYNC_LIMIT = 1 << 30     # bytes of flag buffer we are willing to over-allocate to avoid a host sync
 validate_indices = True          # bounds-check candidate edges on the host side (one sync per batch)
 stage_timer = None               # optional object with .mark(name): bench.py records HIP events between stages
+LN_WIDTHS = (16, 32, 64, 128, 256, 512)   # row widths of the lane-group kernels (LayerNorm, pooling backward)
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 
 
@@ -167,6 +168,22 @@ def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights
     return out[0], out[1], out[2]
 
 
+def cn_gather_backward(rowptrA, colA, src, dst, off, flags, wc, weights: Tensor, h: Tensor, g1: Tensor, g2: Tensor,
+                       g3: Tensor, order: Optional[Tensor] = None) -> Tensor:
+    """Gradient of (xcn1, xcn2, xij) with respect to h."""
+    B, H = src.numel(), h.shape[1]
+    for t, nm in ((g1, "g1"), (g2, "g2"), (g3, "g3")):
+        if _req(t, torch.float32, nm, 2).shape != (B, H):
+            raise ValueError(f"{nm}: expected [{B}, {H}]")
+    if H not in LN_WIDTHS:
+        raise NotImplementedError(f"pooling backward supports hidden widths {LN_WIDTHS}, got {H}")
+    dh = torch.zeros_like(h)
+    check(_lib.lib().ocn_cn_gather_backward(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off),
+                                            ptr(flags), ptr(wc), ptr(weights), ptr(h), H, ptr(g1), ptr(g2), ptr(g3),
+                                            ptr(dh), stream_ptr()), "ocn_cn_gather_backward")
+    return dh
+
+
 SPMM_MODES = {"sum": 0, "add": 0, "mean": 1, "max": 2}
 
 
@@ -218,9 +235,6 @@ def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int):
         check(l.ocn_spgemm_pattern_fill(ptr(rowptrA), ptr(colA), n, ptr(rowptrB), ptr(colB), n_cols_b,
                                         ptr(rowptrC), ptr(colC), stream_ptr()), "ocn_spgemm_pattern_fill")
     return rowptrC, colC
-
-
-LN_WIDTHS = (16, 32, 64, 128, 256, 512)
 
 
 def rows_ln_relu(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu: bool, inplace: bool = False) -> Tensor:

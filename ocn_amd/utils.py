@@ -92,6 +92,23 @@ class CNState:
         return ops.cn_gather(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off,
                              self.flags, self.wc, weights, h, order=self.order)
 
+    def gather_backward(self, weights: Tensor, h: Tensor, g1: Tensor, g2: Tensor, g3: Tensor) -> Tensor:
+        return ops.cn_gather_backward(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off, self.flags,
+                                      self.wc, weights, h, g1.contiguous(), g2.contiguous(), g3.contiguous(),
+                                      order=self.order)
+
+    def cn5_batch_innerprod(self) -> Tensor:
+        """Σ (cn2 ⊙ ncn1) of this batch (model.py:2241-2244), from the integer column counts:
+        every entry in both sets contributes 1/S1 of its column.  Pattern route only."""
+        if self.walk:
+            raise NotImplementedError("running inner product of the walk-count route (training of the ppa / "
+                                      "citation2 drivers) is not built yet")
+        hc = self.hist_counts()
+        n1 = hc[:, 0]
+        nb = n1 + hc[:, 1] - hc[:, 2]
+        inv1 = torch.where(n1 >= 2, 1.0 / n1.clamp(min=1).to(torch.float32), torch.zeros((), device=n1.device))
+        return (nb.to(torch.float32) * inv1).sum()
+
     def materialize(self, bit: int) -> SparseTensor:
         """[B, N] matrix of the entries whose flag has ``bit`` set; values 1.0, or the walk counts
         for bit 2 of the valued route (host-side format conversion for tests; not on the product

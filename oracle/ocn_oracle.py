@@ -298,6 +298,19 @@ def cn5_pool(x: Tensor, cn1: SpM, cn2: SpM, innerprod: Tensor):
     return xcn1, xcn2, aux
 
 
+def cn5_batch_innerprod(cn1: SpM, cn2: SpM) -> Tensor:
+    """innerprod1 in training mode (model.py:2241-2244): Σ of the Hadamard product of cn2 and the
+    column-normalised cn1 (step 1 of A.3), in the entry order of cn2."""
+    S1 = col_sum(cn1)
+    S1[S1 == 0] = 1
+    inv1 = 1 / S1
+    inv1[~(S1 != 1)] = 0
+    k1, k2 = spm2elem(cn1), spm2elem(cn2)
+    idx = torch.searchsorted(k1, k2).clamp_(max=max(k1.numel() - 1, 0))
+    hit = (k1[idx] == k2) if k1.numel() else torch.zeros_like(k2, dtype=torch.bool)
+    return (cn2.val[hit] * (inv1[cn1.col] * cn1.val)[idx[hit]]).sum()
+
+
 def cn5_forward(sd: Dict[str, Tensor], x: Tensor, cn1: SpM, cn2: SpM, tar_ei: Tensor,
                 ln: bool = False, tailact: bool = False, twolayerlin: bool = False) -> Tensor:
     xcn1, xcn2, _ = cn5_pool(x, cn1, cn2, sd["innerprod"])

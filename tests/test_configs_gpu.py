@@ -116,3 +116,53 @@ def test_score_edges_equals_the_drivers_batch_loop(hiplib):
                                edges[perm].t()).squeeze() for perm in PermIterator(DEV, edges.shape[0], 2048, False)])
     got = score_edges(pred, h, adj, adj2, edges, 2048)
     assert got.shape == (5000,) and torch.equal(got, loop)
+
+
+def test_train_loop_like_the_reference_driver(hiplib):
+    """The body of train() in NeighborOverlap_large.py:28-94 (maskinput, A² per batch, positive and
+    negative passes, logsigmoid loss, Adam) written against ocn_amd: runs, produces finite
+    gradients for encoder and predictor, and the loss goes down."""
+    import torch.nn.functional as F
+    import ocn_amd.model as M
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import PermIterator, adjoverlap
+    ei, n, shape = dataset_like("cora", seed=1)
+    pos_train_edge = ei.to(DEV)                                   # [2, E], each undirected edge once
+    H, fin = 64, 48
+    torch.manual_seed(0)
+    x = torch.randn(n, fin, device=DEV)
+    model = M.GCN(fin, H, H, 1, 0.05, True, False, -1, "puregcn", True, 0.0, xdropout=0.3, taildropout=0.1).to(DEV)
+    predictor = M.predictor_dict["cn5"](H, H, 1, 3, 0.05, 0.0, True, use_xlin=True, tailact=True).to(DEV)
+    opt = torch.optim.Adam([{"params": model.parameters(), "lr": 0.004}, {"params": predictor.parameters(), "lr": 0.003}])
+    args = SimpleNamespace(sum=0.0, adj2byblock=False)
+    negedge = torch.randint(0, n, pos_train_edge.shape, device=DEV)
+    losses = []
+    for epoch in range(6):
+        model.train(); predictor.train()
+        adjmask = torch.ones_like(pos_train_edge[0], dtype=torch.bool)
+        tot = []
+        for perm in PermIterator(DEV, adjmask.shape[0], 1152):
+            opt.zero_grad()
+            adjmask[perm] = 0
+            tei = pos_train_edge[:, adjmask]
+            adj = SparseTensor.from_edge_index(tei, sparse_sizes=(n, n)).to_device(DEV, non_blocking=True)
+            adjmask[perm] = 1
+            adj = adj.to_symmetric()
+            h = model(x, adj)
+            edge = pos_train_edge[:, perm]
+            spadj = adj.to_torch_sparse_coo_tensor()
+            adj2 = SparseTensor.from_torch_sparse_coo_tensor(spadj @ spadj, False)
+            pos = predictor.multidomainforward(h, adj, adjoverlap(adj, adj, edge, False), adjoverlap(adj, adj2, edge, False),
+                                               edge, args, cndropprobs=[])
+            edge = negedge[:, perm]
+            neg = predictor.multidomainforward(h, adj, adjoverlap(adj, adj, edge, []), adjoverlap(adj, adj2, edge, []),
+                                               edge, args, cndropprobs=[])
+            loss = -F.logsigmoid(pos).mean() - F.logsigmoid(-neg).mean()
+            loss.backward()
+            for p in list(model.parameters()) + [q for nme, q in predictor.named_parameters() if "xcnlin" not in nme and "xcn4lin" not in nme and "xlin" not in nme]:
+                assert p.grad is not None and torch.isfinite(p.grad).all()
+            opt.step()
+            tot.append(loss.item())
+        losses.append(sum(tot) / len(tot))
+    assert losses[-1] < losses[0] - 0.05, losses
+    assert predictor.innerprod.item() != 0.0 and predictor.n > 0

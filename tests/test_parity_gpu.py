@@ -128,15 +128,80 @@ def test_predictor_scores(case, name, ln, tailact, two):
     assert close(out, ref), (out.cpu() - ref).abs().max()
 
 
-def test_predictor_train_mode_refuses_backward(case):
+@pytest.mark.parametrize("name", ["cn5", "cn7"])
+def test_backward_matches_oracle_autograd(case, name):
+    """Training drop-in: gradients w.r.t. the embeddings and every used parameter against torch
+    autograd through the oracle's op sequence (fp32 atomics: tolerance, not bits)."""
+    if case.B > 4096:
+        pytest.skip("oracle autograd at this size takes minutes")
     from ocn_amd.model import predictor_dict
     from ocn_amd.utils import adjoverlap
-    pred = predictor_dict["cn5"](16, 16, 1, 3, 0.0).to(DEV).train()
+    H = 32
+    torch.manual_seed(case.seed + 17)
+    x = torch.randn(case.n, H)
+    pred = predictor_dict[name](H, H, 1, 3, 0.0, 0.0, True).eval()       # eval + enable_grad: no dropout noise
+    args = SimpleNamespace(sum=1.0)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in pred.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    ref = (O.cn5_forward(sd, xr, case.ocn1, case.ocn2, case.e, True) if name == "cn5"
+           else O.cn7_forward(sd, xr, case.ocn1, case.ocn2, case.e, args.sum, True))
+    wgt = torch.randn(case.B, 1, generator=torch.Generator().manual_seed(1))
+    (ref * wgt).sum().backward()
+    pred = pred.to(DEV)
     e = case.e.to(DEV)
-    x = torch.randn(case.n, 16, device=DEV)
-    with pytest.raises(NotImplementedError):
-        pred.multidomainforward(x, case.adj, adjoverlap(case.adj, case.adj, e),
-                                adjoverlap(case.adj, case.adj2, e), e)
+    xd = x.to(DEV).requires_grad_(True)
+    out = pred(xd, case.adj, adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e), e, args)
+    assert out.requires_grad and close(out, ref)
+    (out * wgt.to(DEV)).sum().backward()
+    scale = xr.grad.abs().max().item()
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 2e-5 * max(1.0, scale)
+    for k, p in pred.named_parameters():
+        if sd[k].grad is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, k      # xcnlin / xcn4lin are never used
+            continue
+        g = sd[k].grad
+        assert (p.grad.cpu() - g).abs().max().item() <= 2e-5 * max(1.0, g.abs().max().item()), k
+
+
+def test_training_mode_updates_running_innerprod(case):
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    H = 16
+    pred = predictor_dict["cn5"](H, H, 1, 3, 0.0).to(DEV).train()
+    e = case.e.to(DEV)
+    x = torch.randn(case.n, H, device=DEV, requires_grad=True)
+    ip1 = O.cn5_batch_innerprod(case.ocn1, case.ocn2).item()
+    out = pred.multidomainforward(x, case.adj, adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e), e)
+    out.sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    assert pred.innerprod.item() == pytest.approx(ip1, rel=1e-5, abs=1e-6) and pred.n == 1
+    pred.multidomainforward(x, case.adj, adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e), e)
+    assert pred.innerprod.item() == pytest.approx(ip1, rel=1e-5, abs=1e-6) and pred.n == 2   # mean of two equal batches
+
+
+@pytest.mark.parametrize("conv", ["puregcn", "gin", "gcn", "puremean"])
+def test_encoder_backward_matches_oracle_autograd(hiplib, conv):
+    import ocn_amd.model as M
+    n, H = 400, 32
+    oadj = make_graph(n, 8, 60, 33, isolated=4)
+    adj = to_product(oadj, DEV)
+    torch.manual_seed(8)
+    enc = M.GCN(H, H, H, 2, 0.0, True, True, -1, conv, True).eval()
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in enc.state_dict().items()}
+    x = torch.randn(n, H)
+    xr = x.clone().requires_grad_(True)
+    ref = O.gcn_forward(sd, xr, oadj, num_layers=2, conv_fn=conv, ln=True, res=True, jk=True)
+    wgt = torch.randn(n, H, generator=torch.Generator().manual_seed(2))
+    (ref * wgt).sum().backward()
+    enc = enc.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    out = enc(xd, adj)
+    assert close(out, ref, atol=2e-5, rtol=2e-5)
+    (out * wgt.to(DEV)).sum().backward()
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 3e-5 * max(1.0, xr.grad.abs().max().item())
+    for k, p in enc.named_parameters():
+        g = sd[k].grad
+        assert g is not None and (p.grad.cpu() - g).abs().max().item() <= 3e-5 * max(1.0, g.abs().max().item()), k
 
 
 # ---- golden: hand-derived Appendix C --------------------------------------------------------
