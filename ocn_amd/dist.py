@@ -4,7 +4,7 @@ The reference is single-device; this is the new data-parallel la
 for.  The adjacency, A², the embeddings and the weights are replicated; a candidate batch is cut
 into contiguous slices, one per rank.  Because the predictors normalise per column over the WHOLE
 batch (``cn.sum(dim=0)``, model.py:2261,3114), ranks exchange exactly one thing before pooling: the
-int32 per-column histograms {n1, n2, n_union} (sum all-reduce — integer, so exact and
+per-column histograms {n1, n2, n_union, walks} (packed int64, sum all-reduce — integer, so exact and
 order-independent; cn5's ``scale`` and S2 are functions of those counts and need no extra
 collective).  Scores come back with one all-gather.
 """
@@ -28,10 +28,22 @@ def shard_bounds(total: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
+def _host_staged(t: Tensor, group) -> bool:
+    """gloo rehearsals (several ranks on one GPU, CPU tests) move device tensors through the host;
+    the production backend is RCCL ("nccl"), which works on device memory directly."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def allreduce_hist(hist: Tensor, group=None) -> Tensor:
-    """In-place sum of the [N, 4] int32 histograms over the edge shards."""
+    """In-place sum of the packed per-column histograms (int64 [N, 2]: integer fields, so the sum is
+    exact and order-independent) over the edge shards."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+        if _host_staged(hist, group):
+            tmp = hist.cpu()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+            hist.copy_(tmp)
+        else:
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
     return hist
 
 
@@ -44,8 +56,13 @@ def gather_scores(local: Tensor, total: int, group=None) -> Tensor:
     width = max(e - s for s, e in bounds)
     pad = local.new_zeros((width,) + tuple(local.shape[1:]))
     pad[: local.shape[0]] = local
-    out = local.new_empty((world * width,) + tuple(local.shape[1:]))
-    dist.all_gather_into_tensor(out, pad, group=group)
+    if _host_staged(local, group):
+        parts = [torch.empty_like(pad, device="cpu") for _ in range(world)]
+        dist.all_gather(parts, pad.cpu(), group=group)
+        out = torch.cat(parts, dim=0).to(local.device)
+    else:
+        out = local.new_empty((world * width,) + tuple(local.shape[1:]))
+        dist.all_gather_into_tensor(out, pad, group=group)
     if all(e - s == width for s, e in bounds):
         return out
     return torch.cat([out[r * width: r * width + (e - s)] for r, (s, e) in enumerate(bounds)], dim=0)

@@ -1,0 +1,73 @@
+"""GPU rehearsal of the edge-sharded path: two ranks share the one GPU of the test box and talk over
+gloo (the production backend is RCCL, which the driver exercises on the 8-GPU node).  The sharded
+scores must equal the single-process scores of the same global batch bit for bit: the only thing
+exchanged before pooling is an integer histogram."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(seed=0):
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.synth import dataset_like, sample_edges
+    dev = torch.device("cuda:0")
+    ei, n, _ = dataset_like("collab", seed=seed, scale=0.03)
+    adj = SparseTensor.from_edge_index(ei.to(dev), sparse_sizes=(n, n)).to_symmetric()
+    sp = adj.to_torch_sparse_coo_tensor()
+    adj2 = SparseTensor.from_torch_sparse_coo_tensor(sp @ sp, False)
+    r, c, _ = adj.coo()
+    edges = sample_edges(r.cpu(), c.cpu(), n, 6001, seed=5).to(dev)          # does not divide by 2
+    torch.manual_seed(3)
+    h = torch.randn(n, 64, device=dev)
+    preds = {k: predictor_dict[k](64, 64, 1, 3, 0.0, 0.0, True).to(dev).eval() for k in ("cn5", "cn7")}
+    with torch.no_grad():
+        preds["cn5"].innerprod.fill_(12.5)
+    return dev, adj, adj2, edges, h, preds
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from types import SimpleNamespace
+        from ocn_amd.dist import sharded_predict
+        dev, adj, adj2, edges, h, preds = _setup()
+        args = SimpleNamespace(sum=2.74)
+        with torch.no_grad():
+            out = {k: sharded_predict(p, h, adj, adj2, edges, args).cpu() for k, p in preds.items()}
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_equal_single_process(hiplib):
+    from types import SimpleNamespace
+    from ocn_amd.utils import adjoverlap
+    dev, adj, adj2, edges, h, preds = _setup()
+    args = SimpleNamespace(sum=2.74)
+    with torch.no_grad():
+        single = {k: p(h, adj, adjoverlap(adj, adj, edges), adjoverlap(adj, adj2, edges), edges, args).cpu()
+                  for k, p in preds.items()}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, out in res:
+        for k in single:
+            assert out[k].shape == single[k].shape
+            assert torch.equal(out[k], single[k]), f"rank {rank} {k}: sharded scores differ from the single-device batch"

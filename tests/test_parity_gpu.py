@@ -502,3 +502,24 @@ def test_processing_order_is_a_permutation_grouped_by_source(hiplib):
     assert torch.equal(torch.sort(order).values, torch.arange(B, device=DEV))
     s = src[order]
     assert bool((s[1:] >= s[:-1]).all())
+
+
+@pytest.mark.parametrize("ip", [0.37, 37.5, 2500.0, -3.0])
+def test_cn5_scores_with_trained_innerprod(case, ip):
+    """A trained checkpoint carries innerprod != 0 (running mean of Σ cn2 ⊙ ncn1 over training
+    batches, typically 1e1..1e4): the orthogonalisation branch must hold the 1e-5 bar too."""
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    H = 64
+    torch.manual_seed(case.seed + 3)
+    x = torch.randn(case.n, H)
+    pred = predictor_dict["cn5"](H, H, 1, 3, 0.0, 0.0, True, use_xlin=True, tailact=True).eval()
+    with torch.no_grad():
+        pred.innerprod.fill_(ip)
+    sd = {k: v.detach().clone() for k, v in pred.state_dict().items()}
+    ref = O.cn5_forward(sd, x, case.ocn1, case.ocn2, case.e, True, True)
+    e = case.e.to(DEV)
+    with torch.no_grad():
+        out = pred.to(DEV)(x.to(DEV), case.adj, adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e), e)
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= 1e-5 + 1e-5 * ref.abs().max().item(), err
