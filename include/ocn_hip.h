@@ -51,6 +51,11 @@ int64_t ocn_order_workspace_bytes(int64_t n_nodes);
 int ocn_order_by_node(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* order, void* workspace,
                       void* stream);
 
+/* Work-item offsets of the walk route: out[slot] = sum over earlier processing slots of
+ * ceil(deg_A(src[order[slot]]) / chunk), out[B] = number of items (chunk = ocn_walk_chunk()). */
+int ocn_chunk_offsets(const int64_t* rowptrA, const int64_t* src, const int64_t* order, int64_t B,
+                      int32_t chunk, int64_t* out, void* workspace, void* stream);
+
 /* Exclusive scan of int32 counts into int64 offsets (out[n] = total). */
 int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, void* stream);
 
@@ -77,10 +82,13 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA,
  * 78-104) without forming Ej·A: cn1 = N(i) ∩ N(j) as above; cn2[e,k] = |N(k) ∩ N(j)| (number of
  * 2-walks j -> k) for k in N(i), kept where > 0.  wc[off[e]+p] receives the walk count, hist[k]
  * additionally accumulates walks = sum of the counts of column k; cnt2[e] = number of non-zero
- * entries of cn2 row e. */
+ * entries of cn2 row e.  Work is cut into items of ocn_walk_chunk() neighbours of i (chunk_off from
+ * ocn_chunk_offsets), so hub source nodes spread over many workgroups; cnt1 / cnt2 must be ZERO on
+ * entry (a row's items add into them). */
+int32_t ocn_walk_chunk(void);
 int ocn_cn_walk_flags(const int64_t* rowptrA, const int32_t* colA,
                       const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
-                      const int64_t* off, uint8_t* flags, int32_t* wc, int64_t flags_cap,
+                      const int64_t* chunk_off, const int64_t* off, uint8_t* flags, int32_t* wc, int64_t flags_cap,
                       uint64_t* hist /* [N][2] */, int32_t* cnt1, int32_t* cnt2,
                       int32_t* status, void* stream);
 
@@ -102,11 +110,14 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream);
  * 3213-3216) in one pass.  xcn1[e] = sum_{k in cn1_e} w1[k] h[k]; xcn2[e] = sum over the
  * union pattern as above; xij[e] = h[i] (.) h[j]; entries in ascending column order, fp32
  * multiply then add.  wc = per-neighbour cn2 values of the walk route or NULL (all 1.0).
- * h is [N][H] row-major fp32; outputs [B][H]. */
+ * h is [N][H] row-major fp32; outputs [B][H].  max_row_len = longest row of A (upper bound):
+ * batch rows whose source row exceeds 1024 entries are pooled by a whole workgroup, in 256*4/H
+ * contiguous segments whose partial sums are added in segment order (everything else keeps the
+ * strictly sequential ascending-column sum). */
 int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA,
                   const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                   const int64_t* off, const uint8_t* flags, const int32_t* wc,
-                  const float* weights /* [N][4] */, const float* h, int32_t H,
+                  const float* weights /* [N][4] */, const float* h, int32_t H, int64_t max_row_len,
                   float* xcn1, float* xcn2, float* xij, void* stream);
 
 /* Backward of the pooling with respect to h (training drop-in): for upstream

@@ -140,67 +140,83 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
 // K1 (walk counts): the pygho route of NeighborOverlap_large_ppa.py:147-173 without A².
 // cn1 = N(i) ∩ N(j); cn2[e,k] = |N(k) ∩ N(j)| for k in N(i) (number of 2-walks j -> k), kept if > 0.
 // ---------------------------------------------------------------------------------------------
-#define WALK_CAP 1024
+#define WALK_CAP 2048
+#define WALK_CHUNK 64       /* neighbours of i per work item */
 
+// Work item = (batch row, chunk of WALK_CHUNK neighbours k of i); items are enumerated through the
+// exclusive scan chunk_off[] so that a hub source node is spread over many workgroups instead of
+// serialising one.  Per item: N(j) staged in LDS (if it fits); the four waves take the chunk's k
+// round-robin; for each k the 64 lanes stride over N(k) (one coalesced row read) and look every
+// member up in N(j) (LDS binary search); hits are counted with ballots.
 __global__ __launch_bounds__(OCN_BLOCK) void cn_walk_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
-    const i64* __restrict__ off, uint8_t* __restrict__ flags, int32_t* __restrict__ wc, i64 cap,
-    u64* __restrict__ hist, int32_t* __restrict__ cnt1, int32_t* __restrict__ cnt2,
-    int32_t* __restrict__ status) {
-  __shared__ int32_t s_nj[OCN_WPB][WALK_CAP];
+    const i64* __restrict__ chunk_off, const i64* __restrict__ off, uint8_t* __restrict__ flags,
+    int32_t* __restrict__ wc, i64 cap, u64* __restrict__ hist, int32_t* __restrict__ cnt1,
+    int32_t* __restrict__ cnt2, int32_t* __restrict__ status) {
+  __shared__ int32_t s_nj[WALK_CAP];
+  __shared__ int s_cnt[2];
+  __shared__ i64 s_slot;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (blockIdx.x == 0 && threadIdx.x == 0 && off[B] > cap) atomicOr(status, 1);
-  for (i64 e0 = (i64)blockIdx.x * OCN_WPB; e0 < B; e0 += (i64)gridDim.x * OCN_WPB) {
-    const i64 slot = e0 + w;
-    const bool act = slot < B;
-    const i64 e = act ? (order ? order[slot] : slot) : 0;
-    i64 a0 = 0, da = 0, b0 = 0, db = 0, base = 0;
-    if (act) {
-      const i64 i = src[e], j = dst[e];
-      a0 = rowptrA[i]; da = rowptrA[i + 1] - a0;
-      b0 = rowptrA[j]; db = rowptrA[j + 1] - b0;
-      base = off[e];
+  const i64 n_items = chunk_off[B];
+  for (i64 item = blockIdx.x; item < n_items; item += gridDim.x) {
+    if (threadIdx.x == 0) {                    // batch row of this item: last slot with chunk_off[slot] <= item
+      i64 lo = 0, hi = B;
+      while (lo < hi) {
+        const i64 mid = (lo + hi) >> 1;
+        if (chunk_off[mid + 1] <= item) lo = mid + 1; else hi = mid;
+      }
+      s_slot = lo;
+      s_cnt[0] = s_cnt[1] = 0;
     }
+    __syncthreads();
+    const i64 slot = s_slot;
+    const i64 e = order ? order[slot] : slot;
+    const i64 i = src[e], j = dst[e];
+    const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+    const i64 b0 = rowptrA[j], db = rowptrA[j + 1] - b0;
+    const i64 base = off[e];
+    const i64 p_lo = (item - chunk_off[slot]) * WALK_CHUNK;
+    const i64 p_hi = (p_lo + WALK_CHUNK) < da ? (p_lo + WALK_CHUNK) : da;
     const bool nj_lds = db <= WALK_CAP;
     if (nj_lds)
-      for (i64 q = lane; q < db; q += OCN_WAVE) s_nj[w][q] = colA[b0 + q];
+      for (i64 q = threadIdx.x; q < db; q += OCN_BLOCK) s_nj[q] = colA[b0 + q];
     __syncthreads();
     const bool fits = base + da <= cap;
     const int32_t* nj_g = colA + b0;
-    int c1 = 0, c2 = 0;
-    for (i64 p = lane; p < da; p += OCN_WAVE) {
-      const int32_t k = colA[a0 + p];
-      const bool f1 = nj_lds ? sorted_has(&s_nj[w][0], db, k) : sorted_has(nj_g, db, k);
+    for (i64 p = p_lo + w; p < p_hi; p += OCN_WPB) {
+      const int32_t k = colA[a0 + p];                     // wave-uniform
       const i64 k0 = rowptrA[k], dk = rowptrA[k + 1] - k0;
       int walks = 0;
-      if (dk <= db || !nj_lds) {
-        // walk N(k), look each member up in N(j)
-        for (i64 q = 0; q < dk; ++q) {
+      for (i64 q0 = 0; q0 < dk; q0 += OCN_WAVE) {
+        const i64 q = q0 + lane;
+        bool hit = false;
+        if (q < dk) {
           const int32_t m = colA[k0 + q];
-          walks += nj_lds ? sorted_has(&s_nj[w][0], db, m) : sorted_has(nj_g, db, m);
+          hit = nj_lds ? sorted_has(&s_nj[0], db, m) : sorted_has(nj_g, db, m);
         }
-      } else {
-        // N(j) is the shorter list and sits in LDS: look its members up in N(k)
-        for (i64 q = 0; q < db; ++q) walks += sorted_has(colA + k0, dk, s_nj[w][q]);
+        walks += __popcll(__ballot(hit));
       }
-      const bool f2 = walks > 0;
-      if (fits) {
-        flags[base + p] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
-        wc[base + p] = walks;
+      if (lane == 0) {
+        const bool f1 = nj_lds ? sorted_has(&s_nj[0], db, k) : sorted_has(nj_g, db, k);
+        const bool f2 = walks > 0;
+        if (fits) {
+          flags[base + p] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
+          wc[base + p] = walks;
+        }
+        if (f1 | f2) {
+          atomicAdd(hist + 2 * (i64)k, (u64)f1 | ((u64)f2 << HF_BITS) | (1ull << (2 * HF_BITS)));
+          if (f2) atomicAdd(hist + 2 * (i64)k + 1, (u64)walks);
+          if (f1) atomicAdd(&s_cnt[0], 1);
+          if (f2) atomicAdd(&s_cnt[1], 1);
+        }
       }
-      if (f1 | f2) {
-        atomicAdd(hist + 2 * (i64)k, (u64)f1 | ((u64)f2 << HF_BITS) | (1ull << (2 * HF_BITS)));
-        if (f2) atomicAdd(hist + 2 * (i64)k + 1, (u64)walks);
-      }
-      c1 += f1;
-      c2 += f2;
     }
-    c1 = wave_sum(c1);
-    c2 = wave_sum(c2);
-    if (act && lane == 0) {
-      cnt1[e] = c1;
-      cnt2[e] = c2;
+    __syncthreads();
+    if (threadIdx.x == 0) {                    // cnt1 / cnt2 are zero on entry; a row may span several items
+      if (s_cnt[0]) atomicAdd(cnt1 + e, s_cnt[0]);
+      if (s_cnt[1]) atomicAdd(cnt2 + e, s_cnt[1]);
     }
     __syncthreads();
   }
@@ -301,37 +317,21 @@ __device__ __forceinline__ void entry_weights(unsigned f, const float4& w, float
   wb = __fmul_rn(v, w.z);
 }
 
-// LPE lanes cooperate on one edge; each lane owns NV float4 of the H = LPE*NV*4 features.
+// Pool the flagged neighbours at positions [p_begin, p_end) of the source row into acc1 / acc2, in
+// ascending position (= column) order.  LPE lanes cooperate; each lane owns NV float4 of the
+// H = LPE*NV*4 features; four embedding rows are in flight per group.
 template <int LPE, int NV>
-__global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
-    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
-    const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
-    const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
-    const float4* __restrict__ weights, const float* __restrict__ h, int H,
-    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
-  constexpr int GPW = OCN_WAVE / LPE;
+__device__ __forceinline__ void pool_range(i64 p_begin, i64 p_end, i64 a0, i64 base, int gl, int gbase,
+                                           const int32_t* __restrict__ colA, const uint8_t* __restrict__ flags,
+                                           const int32_t* __restrict__ wc, const float4* __restrict__ weights,
+                                           const float4* __restrict__ h4, i64 rowq, float4 (&acc1)[NV],
+                                           float4 (&acc2)[NV]) {
   constexpr int UNR = 4;
-  const int lane = threadIdx.x & 63;
-  const int gl = lane % LPE;
-  const int gbase = lane - gl;
-  const i64 slot = ((i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
-  if (slot >= B) return;                    // whole group leaves together
-  const i64 e = order ? order[slot] : slot;
-  const i64 i = src[e], j = dst[e];
-  const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
-  const i64 base = off[e];
-  const float4* h4 = reinterpret_cast<const float4*>(h);
-  const i64 rowq = H >> 2;                  // float4 per row
-
-  float4 acc1[NV], acc2[NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  for (i64 p0 = 0; p0 < da; p0 += LPE) {
+  for (i64 p0 = p_begin; p0 < p_end; p0 += LPE) {
     const i64 p = p0 + gl;
     int32_t k = 0;
     unsigned f = 0;
-    if (p < da) { k = colA[a0 + p]; f = flags[base + p]; }
+    if (p < p_end) { k = colA[a0 + p]; f = flags[base + p]; }
     float wa = 0.f, wb = 0.f;
     if (f) entry_weights(f, weights[k], wc ? (float)wc[base + p] : 1.0f, wa, wb);
     const bool need = (wa != 0.f) | (wb != 0.f);
@@ -371,6 +371,13 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
       }
     }
   }
+}
+
+template <int LPE, int NV>
+__device__ __forceinline__ void pool_store(i64 e, i64 i, i64 j, int gl, const float4* __restrict__ h4, i64 rowq,
+                                           const float4 (&acc1)[NV], const float4 (&acc2)[NV],
+                                           float* __restrict__ xcn1, float* __restrict__ xcn2,
+                                           float* __restrict__ xij) {
   const float4* hi = h4 + i * rowq + gl;
   const float4* hj = h4 + j * rowq + gl;
   float4* o1 = reinterpret_cast<float4*>(xcn1) + e * rowq + gl;
@@ -383,6 +390,89 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
     o2[v * LPE] = acc2[v];
     o3[v * LPE] = make_float4(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y), __fmul_rn(a.z, b.z),
                               __fmul_rn(a.w, b.w));
+  }
+}
+
+// Source rows longer than this are pooled by a whole workgroup (cn_gather_long_kernel): its lane
+// groups take contiguous segments of the row and the partial sums are added in segment order.
+// Rows up to LONG_ROW keep the strictly sequential ascending-column sum of the reference's spmm.
+#define LONG_ROW 1024
+
+// LPE lanes cooperate on one edge (64/LPE edges per wave).
+template <int LPE, int NV>
+__global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
+    const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
+    const float4* __restrict__ weights, const float* __restrict__ h, int H,
+    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
+  constexpr int GPW = OCN_WAVE / LPE;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane % LPE;
+  const int gbase = lane - gl;
+  const i64 slot = ((i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
+  if (slot >= B) return;                    // whole group leaves together
+  const i64 e = order ? order[slot] : slot;
+  const i64 i = src[e], j = dst[e];
+  const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+  if (da > LONG_ROW) return;                // cn_gather_long_kernel's
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  const i64 rowq = H >> 2;                  // float4 per row
+  float4 acc1[NV], acc2[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  pool_range<LPE, NV>(0, da, a0, off[e], gl, gbase, colA, flags, wc, weights, h4, rowq, acc1, acc2);
+  pool_store<LPE, NV>(e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
+}
+
+// One workgroup per batch row whose source row is longer than LONG_ROW (hub sources): the 256/LPE
+// lane groups pool contiguous segments, partial sums meet in LDS and are added in segment order.
+template <int LPE, int NV>
+__global__ __launch_bounds__(OCN_BLOCK) void cn_gather_long_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
+    const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
+    const float4* __restrict__ weights, const float* __restrict__ h, int H,
+    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
+  constexpr int NG = OCN_BLOCK / LPE;       // lane groups per workgroup
+  __shared__ float4 s_part[NG][2][LPE * NV];
+  const i64 e = blockIdx.x;
+  const i64 i = src[e], j = dst[e];
+  const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+  if (da <= LONG_ROW) return;               // whole workgroup leaves together
+  const int lane = threadIdx.x & 63;
+  const int gl = lane % LPE;
+  const int gbase = lane - gl;
+  const int g = threadIdx.x / LPE;
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  const i64 rowq = H >> 2;
+  i64 seg = (da + NG - 1) / NG;
+  seg = ((seg + LPE - 1) / LPE) * LPE;
+  const i64 pb = (i64)g * seg < da ? (i64)g * seg : da;
+  const i64 pe = pb + seg < da ? pb + seg : da;
+  float4 acc1[NV], acc2[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  pool_range<LPE, NV>(pb, pe, a0, off[e], gl, gbase, colA, flags, wc, weights, h4, rowq, acc1, acc2);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    s_part[g][0][gl + v * LPE] = acc1[v];
+    s_part[g][1][gl + v * LPE] = acc2[v];
+  }
+  __syncthreads();
+  if (g == 0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      float4 t1 = s_part[0][0][gl + v * LPE], t2 = s_part[0][1][gl + v * LPE];
+      for (int q = 1; q < NG; ++q) {
+        const float4 u1 = s_part[q][0][gl + v * LPE], u2 = s_part[q][1][gl + v * LPE];
+        t1.x = __fadd_rn(t1.x, u1.x); t1.y = __fadd_rn(t1.y, u1.y); t1.z = __fadd_rn(t1.z, u1.z); t1.w = __fadd_rn(t1.w, u1.w);
+        t2.x = __fadd_rn(t2.x, u2.x); t2.y = __fadd_rn(t2.y, u2.y); t2.z = __fadd_rn(t2.z, u2.z); t2.w = __fadd_rn(t2.w, u2.w);
+      }
+      acc1[v] = t1;
+      acc2[v] = t2;
+    }
+    pool_store<LPE, NV>(e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
   }
 }
 
@@ -531,19 +621,22 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
 }
 
 int ocn_cn_walk_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
-                      const int64_t* dst, const int64_t* order, int64_t B, const int64_t* off, uint8_t* flags, int32_t* wc,
-                      int64_t flags_cap, uint64_t* hist, int32_t* cnt1, int32_t* cnt2, int32_t* status,
-                      void* stream) {
+                      const int64_t* dst, const int64_t* order, int64_t B, const int64_t* chunk_off,
+                      const int64_t* off, uint8_t* flags, int32_t* wc, int64_t flags_cap, uint64_t* hist,
+                      int32_t* cnt1, int32_t* cnt2, int32_t* status, void* stream) {
   if (B < 0 || flags_cap < 0 || B > (int64_t)HF_MASK) return OCN_EINVAL;
   if (B == 0) return 0;
-  if (!rowptrA || !src || !dst || !off || !hist || !cnt1 || !cnt2 || !status) return OCN_EINVAL;
+  if (!rowptrA || !src || !dst || !chunk_off || !off || !hist || !cnt1 || !cnt2 || !status) return OCN_EINVAL;
   if (flags_cap > 0 && (!flags || !wc)) return OCN_EINVAL;
-  const int grid = grid_for((B + OCN_WPB - 1) / OCN_WPB);
+  // the item count lives on the device (chunk_off[B]); a fixed grid strides over it
+  const int grid = grid_for(4 * B, 256 * 16);
   hipLaunchKernelGGL(cn_walk_kernel, dim3(grid), dim3(OCN_BLOCK), 0, (hipStream_t)stream,
                      (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B,
-                     (const i64*)off, flags, wc, (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
+                     (const i64*)chunk_off, (const i64*)off, flags, wc, (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
   return launch_status();
 }
+
+int32_t ocn_walk_chunk(void) { return WALK_CHUNK; }
 
 int ocn_cn_weights_cn5(uint64_t* hist, int64_t N, const float* innerprod, int32_t* scalars,
                        int32_t valued, void* stream) {
@@ -574,12 +667,17 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream) 
     const i64 epb = (i64)OCN_WPB * (OCN_WAVE / (LPE));                                              \
     hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)),          \
                        dim3(OCN_BLOCK), 0, st, GATHER_ARGS);                                        \
+    if (max_row_len > LONG_ROW)                                                                     \
+      hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV>), dim3((unsigned)B), dim3(OCN_BLOCK), 0,   \
+                         st, (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B,   \
+                         (const i64*)off, flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, \
+                         xij);                                                                      \
   } while (0)
 
 int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
                   const int64_t* dst, const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
-                  const int32_t* wc, const float* weights, const float* h, int32_t H, float* xcn1,
-                  float* xcn2, float* xij, void* stream) {
+                  const int32_t* wc, const float* weights, const float* h, int32_t H,
+                  int64_t max_row_len, float* xcn1, float* xcn2, float* xij, void* stream) {
   if (B < 0 || H <= 0) return OCN_EINVAL;
   if (B == 0) return 0;
   if (!rowptrA || !src || !dst || !off || !weights || !h || !xcn1 || !xcn2 || !xij) return OCN_EINVAL;
@@ -591,7 +689,7 @@ int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* sr
     case 128: LAUNCH_GATHER(32, 1); break;
     case 256: LAUNCH_GATHER(64, 1); break;
     case 512: LAUNCH_GATHER(64, 2); break;
-    default:
+    default:   /* generic widths: every row by one wave, no long-row split */
       hipLaunchKernelGGL(cn_gather_generic, dim3((unsigned)((B + OCN_WPB - 1) / OCN_WPB)),
                          dim3(OCN_BLOCK), 0, st, GATHER_ARGS);
   }

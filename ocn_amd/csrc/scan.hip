@@ -15,6 +15,16 @@ struct DegOfSrc {
     return rowptr[i + 1] - rowptr[i];
   }
 };
+struct ChunksOfSlot {      // ceil(deg(src[order[slot]]) / chunk): work items of a batch row, in processing order
+  const i64* rowptr;
+  const i64* src;
+  const i64* order;
+  i64 chunk;
+  __device__ __forceinline__ i64 operator()(i64 slot) const {
+    const i64 i = src[order ? order[slot] : slot];
+    return (rowptr[i + 1] - rowptr[i] + chunk - 1) / chunk;
+  }
+};
 struct I32In {
   const int32_t* in;
   __device__ __forceinline__ i64 operator()(i64 e) const { return (i64)in[e]; }
@@ -154,6 +164,13 @@ int ocn_edge_offsets(const int64_t* rowptrA, const int64_t* src, int64_t B, int6
   if (!rowptrA || (!src && B > 0)) return OCN_EINVAL;
   DegOfSrc op{(const i64*)rowptrA, (const i64*)src};
   return run_scan(op, B, (i64*)off, workspace, (hipStream_t)stream);
+}
+
+int ocn_chunk_offsets(const int64_t* rowptrA, const int64_t* src, const int64_t* order, int64_t B,
+                      int32_t chunk, int64_t* out, void* workspace, void* stream) {
+  if (!rowptrA || (!src && B > 0) || chunk <= 0) return OCN_EINVAL;
+  ChunksOfSlot op{(const i64*)rowptrA, (const i64*)src, (const i64*)order, (i64)chunk};
+  return run_scan(op, B, (i64*)out, workspace, (hipStream_t)stream);
 }
 
 int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, void* stream) {

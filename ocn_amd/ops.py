@@ -117,12 +117,18 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     flags = torch.empty(max(cap, 1), dtype=torch.uint8, device=dev)
     wc = torch.empty(max(cap, 1), dtype=torch.int32, device=dev) if walk else None
     hist = torch.zeros(n_cols, 2, dtype=torch.int64, device=dev)
-    cnt1 = torch.empty(B, dtype=torch.int32, device=dev)
-    cnt2 = torch.empty(B, dtype=torch.int32, device=dev) if (walk or t2 is not None) else None
+    cnt1 = (torch.zeros if walk else torch.empty)(B, dtype=torch.int32, device=dev)
+    cnt2 = (torch.zeros if walk else torch.empty)(B, dtype=torch.int32, device=dev) if (walk or t2 is not None) else None
+    chunk_off = None
+    if walk:
+        chunk_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
+        check(_lib.lib().ocn_chunk_offsets(ptr(rowptrA), ptr(src), ptr(order), B, _lib.lib().ocn_walk_chunk(),
+                                           ptr(chunk_off), ptr(_ws(B, dev)), stream_ptr()), "ocn_chunk_offsets")
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     _mark("cn_prep")
     if walk:
-        check(_lib.lib().ocn_cn_walk_flags(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags),
+        check(_lib.lib().ocn_cn_walk_flags(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(chunk_off),
+                                           ptr(off), ptr(flags),
                                            ptr(wc), cap, ptr(hist), ptr(cnt1), ptr(cnt2), ptr(status),
                                            stream_ptr()), "ocn_cn_walk_flags")
     else:
@@ -154,7 +160,7 @@ def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
 
 
 def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights: Tensor, h: Tensor,
-              order: Optional[Tensor] = None):
+              order: Optional[Tensor] = None, max_row_len: int = 0):
     _req(weights, torch.float32, "weights", 2)
     _req(h, torch.float32, "h", 2)
     if weights.shape[0] != h.shape[0] or weights.shape[1] != 4:
@@ -162,8 +168,8 @@ def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights
     B, H = src.numel(), h.shape[1]
     out = torch.empty(3, B, H, dtype=torch.float32, device=h.device)
     check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags),
-                                   ptr(wc), ptr(weights), ptr(h), H, ptr(out[0]), ptr(out[1]), ptr(out[2]),
-                                   stream_ptr()), "ocn_cn_gather")
+                                   ptr(wc), ptr(weights), ptr(h), H, int(max_row_len), ptr(out[0]), ptr(out[1]),
+                                   ptr(out[2]), stream_ptr()), "ocn_cn_gather")
     _mark("cn_gather")
     return out[0], out[1], out[2]
 

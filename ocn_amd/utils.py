@@ -90,7 +90,8 @@ class CNState:
 
     def gather(self, weights: Tensor, h: Tensor):
         return ops.cn_gather(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off,
-                             self.flags, self.wc, weights, h, order=self.order)
+                             self.flags, self.wc, weights, h, order=self.order,
+                             max_row_len=self.adj.max_rowcount())
 
     def gather_backward(self, weights: Tensor, h: Tensor, g1: Tensor, g2: Tensor, g3: Tensor) -> Tensor:
         return ops.cn_gather_backward(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off, self.flags,

@@ -316,7 +316,14 @@ def test_hub_rows_longer_than_a_wave(hiplib):
     x = torch.randn(n, 256)
     r1, r2, _ = O.cn5_pool(x, c1, c2, torch.tensor([0.0]))
     g1, g2, _ = st.gather(st.weights_cn5(torch.zeros(1, device=DEV)), x.to(DEV))
-    assert torch.equal(g1.cpu(), r1) and close(g2, r2)
+    assert torch.equal(g1.cpu(), r1)
+    # rows 0 and 1 have the 2999-entry hub as source: they are pooled by a whole workgroup in
+    # segment order, i.e. a different (equally valid) fp32 summation order of ~3000 O(1) terms —
+    # compare relative to the row's magnitude; the short rows stay element-wise tight
+    assert int(adj.storage.rowcount()[0]) > 1024
+    err = (g2.cpu() - r2).abs().max(dim=1).values
+    assert bool((err <= 1e-5 * r2.abs().max(dim=1).values + 1e-5).all()), err
+    assert close(g2[2:], r2[2:])
 
 
 # ---- encoders -----------------------------------------------------------------------------
