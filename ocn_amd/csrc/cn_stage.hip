@@ -140,23 +140,43 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
 // K1 (walk counts): the pygho route of NeighborOverlap_large_ppa.py:147-173 without A².
 // cn1 = N(i) ∩ N(j); cn2[e,k] = |N(k) ∩ N(j)| for k in N(i) (number of 2-walks j -> k), kept if > 0.
 // ---------------------------------------------------------------------------------------------
-#define WALK_CAP 2048
+#define WALK_CAP 2048       /* |N(j)| up to which N(j) becomes an LDS hash set (load factor <= 1/2) */
+#define WALK_HT 4096
 #define WALK_CHUNK 64       /* neighbours of i per work item */
+
+__device__ __forceinline__ unsigned walk_hash(int32_t v) { return ((unsigned)v * 2654435761u) >> 20; }   // 12 bits
+
+__device__ __forceinline__ bool walk_ht_has(const int32_t* ht, int32_t key) {
+  unsigned s = walk_hash(key);
+  for (;;) {
+    const int32_t t = ht[s];
+    if (t == key) return true;
+    if (t < 0) return false;
+    s = (s + 1) & (WALK_HT - 1);
+  }
+}
 
 // Work item = (batch row, chunk of WALK_CHUNK neighbours k of i); items are enumerated through the
 // exclusive scan chunk_off[] so that a hub source node is spread over many workgroups instead of
-// serialising one.  Per item: N(j) staged in LDS (if it fits); the four waves take the chunk's k
-// round-robin; for each k the 64 lanes stride over N(k) (one coalesced row read) and look every
-// member up in N(j) (LDS binary search); hits are counted with ballots.
+// serialising one.  Per item: N(j) becomes an open-addressing hash set in LDS (~1.5 probes per
+// lookup instead of log2 |N(j)|), and the members of the chunk's rows N(k) are FLATTENED: the 256
+// threads sweep the concatenation of the rows (element -> row by a 6-step search of the chunk's
+// prefix sums), so short rows do not idle lanes, no load waits on a per-row pointer chase, and a
+// hub k costs what its length costs.  Hits (rare) bump the row's counter with an LDS atomic.
+// |N(j)| > WALK_CAP falls back to binary search in memory.
 __global__ __launch_bounds__(OCN_BLOCK) void cn_walk_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     const i64* __restrict__ chunk_off, const i64* __restrict__ off, uint8_t* __restrict__ flags,
     int32_t* __restrict__ wc, i64 cap, u64* __restrict__ hist, int32_t* __restrict__ cnt1,
     int32_t* __restrict__ cnt2, int32_t* __restrict__ status) {
-  __shared__ int32_t s_nj[WALK_CAP];
-  __shared__ int s_cnt[2];
+  __shared__ int32_t s_ht[WALK_HT];
+  __shared__ int s_pre[2 * WALK_CHUNK];      // exclusive prefix of the chunk's row lengths; [nk..] = INT_MAX
+  __shared__ i64 s_k0[WALK_CHUNK];
+  __shared__ int32_t s_k[WALK_CHUNK];
+  __shared__ int s_walks[WALK_CHUNK];
   __shared__ i64 s_slot;
+  __shared__ int s_total;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (blockIdx.x == 0 && threadIdx.x == 0 && off[B] > cap) atomicOr(status, 1);
   const i64 n_items = chunk_off[B];
@@ -168,8 +188,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_walk_kernel(
         if (chunk_off[mid + 1] <= item) lo = mid + 1; else hi = mid;
       }
       s_slot = lo;
-      s_cnt[0] = s_cnt[1] = 0;
     }
+    for (int q = threadIdx.x; q < WALK_HT; q += OCN_BLOCK) s_ht[q] = -1;
     __syncthreads();
     const i64 slot = s_slot;
     const i64 e = order ? order[slot] : slot;
@@ -178,45 +198,70 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_walk_kernel(
     const i64 b0 = rowptrA[j], db = rowptrA[j + 1] - b0;
     const i64 base = off[e];
     const i64 p_lo = (item - chunk_off[slot]) * WALK_CHUNK;
-    const i64 p_hi = (p_lo + WALK_CHUNK) < da ? (p_lo + WALK_CHUNK) : da;
+    const int nk = (int)(((p_lo + WALK_CHUNK) < da ? (p_lo + WALK_CHUNK) : da) - p_lo);
     const bool nj_lds = db <= WALK_CAP;
-    if (nj_lds)
-      for (i64 q = threadIdx.x; q < db; q += OCN_BLOCK) s_nj[q] = colA[b0 + q];
-    __syncthreads();
-    const bool fits = base + da <= cap;
     const int32_t* nj_g = colA + b0;
-    for (i64 p = p_lo + w; p < p_hi; p += OCN_WPB) {
-      const int32_t k = colA[a0 + p];                     // wave-uniform
-      const i64 k0 = rowptrA[k], dk = rowptrA[k + 1] - k0;
-      int walks = 0;
-      for (i64 q0 = 0; q0 < dk; q0 += OCN_WAVE) {
-        const i64 q = q0 + lane;
-        bool hit = false;
-        if (q < dk) {
-          const int32_t m = colA[k0 + q];
-          hit = nj_lds ? sorted_has(&s_nj[0], db, m) : sorted_has(nj_g, db, m);
-        }
-        walks += __popcll(__ballot(hit));
+    if (w == 0) {                              // the chunk's rows: ids, starts, prefix sums of lengths
+      int32_t k = 0;
+      i64 k0 = 0, dk = 0;
+      if (lane < nk) { k = colA[a0 + p_lo + lane]; k0 = rowptrA[k]; dk = rowptrA[k + 1] - k0; }
+      const i64 incl = wave_incl_scan(dk, lane);           // <= 64 x max degree: far below 2^31
+      const i64 excl = incl - dk;
+      s_pre[lane] = lane < nk ? (int)excl : 0x7fffffff;
+      s_pre[lane + WALK_CHUNK] = 0x7fffffff;               // padding: the 6-step search below never branches on nk
+      s_k[lane] = k; s_k0[lane] = k0; s_walks[lane] = 0;
+      if (lane == OCN_WAVE - 1) s_total = (int)incl;
+    } else if (nj_lds) {                       // meanwhile the other waves hash N(j)
+      for (i64 q = threadIdx.x - OCN_WAVE; q < db; q += OCN_BLOCK - OCN_WAVE) {
+        const int32_t v = colA[b0 + q];
+        unsigned s = walk_hash(v);
+        while (atomicCAS(&s_ht[s], -1, v) != -1) s = (s + 1) & (WALK_HT - 1);
       }
-      if (lane == 0) {
-        const bool f1 = nj_lds ? sorted_has(&s_nj[0], db, k) : sorted_has(nj_g, db, k);
-        const bool f2 = walks > 0;
-        if (fits) {
-          flags[base + p] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
-          wc[base + p] = walks;
+    }
+    __syncthreads();
+    const int total = s_total;
+    constexpr int WU = 4;                      // independent element chains in flight per thread
+    for (int x0 = threadIdx.x; x0 < total; x0 += WU * OCN_BLOCK) {
+      int row[WU];
+      int32_t m[WU];
+#pragma unroll
+      for (int u = 0; u < WU; ++u) {
+        const int x = x0 + u * OCN_BLOCK;
+        int lo = 0;                            // row of element x: last t with s_pre[t] <= x (s_pre[0] = 0)
+#pragma unroll
+        for (int st = WALK_CHUNK / 2; st > 0; st >>= 1)
+          if (s_pre[lo + st] <= x) lo += st;
+        row[u] = lo;
+        m[u] = x < total ? colA[s_k0[lo] + (x - s_pre[lo])] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < WU; ++u) {
+        if (m[u] >= 0 && (nj_lds ? walk_ht_has(s_ht, m[u]) : sorted_has(nj_g, db, m[u])))
+          atomicAdd(&s_walks[row[u]], 1);
+      }
+    }
+    __syncthreads();
+    if (w == 0) {
+      bool f1 = false, f2 = false;
+      if (lane < nk) {
+        const int32_t k = s_k[lane];
+        const int walks = s_walks[lane];
+        f1 = nj_lds ? walk_ht_has(s_ht, k) : sorted_has(nj_g, db, k);
+        f2 = walks > 0;
+        if (base + da <= cap) {
+          flags[base + p_lo + lane] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
+          wc[base + p_lo + lane] = walks;
         }
         if (f1 | f2) {
           atomicAdd(hist + 2 * (i64)k, (u64)f1 | ((u64)f2 << HF_BITS) | (1ull << (2 * HF_BITS)));
           if (f2) atomicAdd(hist + 2 * (i64)k + 1, (u64)walks);
-          if (f1) atomicAdd(&s_cnt[0], 1);
-          if (f2) atomicAdd(&s_cnt[1], 1);
         }
       }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {                    // cnt1 / cnt2 are zero on entry; a row may span several items
-      if (s_cnt[0]) atomicAdd(cnt1 + e, s_cnt[0]);
-      if (s_cnt[1]) atomicAdd(cnt2 + e, s_cnt[1]);
+      const int c1 = __popcll(__ballot(f1)), c2 = __popcll(__ballot(f2));
+      if (lane == 0) {                         // cnt1 / cnt2 are zero on entry; a row may span several items
+        if (c1) atomicAdd(cnt1 + e, c1);
+        if (c2) atomicAdd(cnt2 + e, c2);
+      }
     }
     __syncthreads();
   }
