@@ -74,8 +74,8 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA,
                  const int64_t* rowptrT1, const int32_t* colT1,
                  const int64_t* rowptrT2, const int32_t* colT2,
                  const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
-                 const int64_t* off, uint8_t* flags, int64_t flags_cap,
-                 uint64_t* hist /* [N][2] */, int32_t* cnt1, int32_t* cnt2,
+                 int64_t n_cols, const int64_t* off, uint8_t* flags, int64_t flags_cap,
+                 uint64_t* hist /* [n_cols][2] */, int32_t* cnt1, int32_t* cnt2,
                  int32_t* status, void* stream);
 
 /* The pygho route get_cn1_cn2 (NeighborOverlap_large_ppa.py:147-173, NeighborOverlapCitation2.py:

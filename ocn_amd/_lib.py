@@ -26,7 +26,8 @@ SIGNATURES = {
     "ocn_scan_i32": (c_int32, [_P, c_int64, _P, _P, _P]),
     "ocn_order_workspace_bytes": (c_int64, [c_int64]),
     "ocn_order_by_node": (c_int32, [_P, c_int64, c_int64, _P, _P, _P]),
-    "ocn_cn_flags": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, _P]),
+    "ocn_cn_flags": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, _P, _P, c_int64, _P, _P, _P, _P,
+                               _P]),
     "ocn_chunk_offsets": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P, _P]),
     "ocn_walk_chunk": (c_int32, []),
     "ocn_cn_walk_flags": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),

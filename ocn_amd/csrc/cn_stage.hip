@@ -48,7 +48,7 @@ __device__ __forceinline__ bool sampled_has(const int32_t* samp, const int32_t* 
 // ---------------------------------------------------------------------------------------------
 // K1 (pattern): flags for N(src) against the rows of dst in T1 (and T2)
 // ---------------------------------------------------------------------------------------------
-#define T1_CAP 256
+#define T1_CAP 1024
 #ifndef OCN_X_G
 #define OCN_X_G 64     /* lanes per candidate edge; tools/kbench.py overrides it for timing experiments */
 #endif
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     const i64* __restrict__ rowptrT1, const int32_t* __restrict__ colT1,
     const i64* __restrict__ rowptrT2, const int32_t* __restrict__ colT2,
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
-    const i64* __restrict__ off, uint8_t* __restrict__ flags, i64 cap,
+    i64 n_cols, const i64* __restrict__ off, uint8_t* __restrict__ flags, i64 cap,
     u64* __restrict__ hist, int32_t* __restrict__ cnt1, int32_t* __restrict__ cnt2,
     int32_t* __restrict__ status) {
   constexpr int GPB = OCN_BLOCK / G;
@@ -88,7 +88,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     const bool t1_lds = db <= T1_CAP;
     if (t1_lds)
       for (i64 q = gl; q < db; q += G) s_t1[g][q] = colT1[b0 + q];
-    if (HAS_T2) {
+    const bool t2_full = HAS_T2 && dc == n_cols;        // a full row (dense A², e.g. ddi) contains every column
+    if (HAS_T2 && !t2_full) {
       if (dc > OCN_WAVE) {
 #pragma unroll
         for (int q = gl; q < OCN_WAVE; q += G) s_t2[g][q] = colT2[c0 + (((i64)q * dc) >> 6)];
@@ -111,7 +112,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
       f2 = (k & 1) == 0;
 #else
       if (HAS_T2)
-        f2 = dc > OCN_WAVE ? sampled_has(&s_t2[g][0], colT2 + c0, dc, k) : sorted_has(&s_t2[g][0], dc, k);
+        f2 = t2_full ? true
+                     : (dc > OCN_WAVE ? sampled_has(&s_t2[g][0], colT2 + c0, dc, k) : sorted_has(&s_t2[g][0], dc, k));
 #endif
 #ifndef OCN_X_NOFLAGS
       if (fits) flags[base + p] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
@@ -643,8 +645,8 @@ extern "C" {
 int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* rowptrT1,
                  const int32_t* colT1, const int64_t* rowptrT2, const int32_t* colT2,
                  const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
-                 const int64_t* off, uint8_t* flags, int64_t flags_cap, uint64_t* hist, int32_t* cnt1,
-                 int32_t* cnt2, int32_t* status, void* stream) {
+                 int64_t n_cols, const int64_t* off, uint8_t* flags, int64_t flags_cap, uint64_t* hist,
+                 int32_t* cnt1, int32_t* cnt2, int32_t* status, void* stream) {
   if (B < 0 || flags_cap < 0 || B > (int64_t)HF_MASK) return OCN_EINVAL;
   if (B == 0) return 0;
   if (!rowptrA || !rowptrT1 || !src || !dst || !off || !hist || !cnt1 || !status) return OCN_EINVAL;
@@ -655,13 +657,13 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
   if (rowptrT2)
     hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, true>), dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
                        colA, (const i64*)rowptrT1, colT1, (const i64*)rowptrT2, colT2, (const i64*)src,
-                       (const i64*)dst, (const i64*)order, (i64)B, (const i64*)off, flags, (i64)flags_cap, (u64*)hist, cnt1,
-                       cnt2, status);
+                       (const i64*)dst, (const i64*)order, (i64)B, (i64)n_cols, (const i64*)off, flags,
+                       (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
   else
     hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, false>), dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
                        colA, (const i64*)rowptrT1, colT1, (const i64*)nullptr, (const int32_t*)nullptr,
-                       (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, (const i64*)off, flags,
-                       (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
+                       (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, (i64)n_cols, (const i64*)off,
+                       flags, (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
   return launch_status();
 }
 

@@ -134,7 +134,7 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     else:
         check(_lib.lib().ocn_cn_flags(ptr(rowptrA), ptr(colA), ptr(t1[0]), ptr(t1[1]),
                                       ptr(t2[0] if t2 else None), ptr(t2[1] if t2 else None),
-                                      ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags), cap, ptr(hist),
+                                      ptr(src), ptr(dst), ptr(order), B, n_cols, ptr(off), ptr(flags), cap, ptr(hist),
                                       ptr(cnt1), ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_flags")
     _mark("cn_flags")
     return order, off, flags, wc, hist, cnt1, cnt2, status
