@@ -88,6 +88,10 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
                 "ocn_amd has no CPU fallback.")
+        # One HIP runtime per process: the torch wheel bundles its own libamdhip64 (same SONAME as
+        # /opt/rocm's).  Importing torch first makes the loader hand that copy to libocn_hip.so too;
+        # the other order would silently run torch on a different runtime (hipErrorNoDevice later).
+        import torch  # noqa: F401
         l = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError if the symbol is not exported
