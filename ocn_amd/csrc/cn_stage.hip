@@ -58,7 +58,12 @@ __device__ __forceinline__ bool sampled_has(const int32_t* samp, const int32_t* 
 // the number of distinct cache lines its scattered probes touch per wave instruction, not by the
 // latency of the chains: lanes that search the SAME rows share the top-of-tree lines, lanes of
 // different edges do not, so one edge per wave wins although most source rows are < 64 long.
-template <int G, bool HAS_T2>
+// LH: the column histogram of this workgroup is kept in LDS (n_cols <= LH_MAX_COLS, i.e. Cora /
+// Citeseer / ddi-sized graphs, where tens of millions of CN entries would otherwise hammer a few
+// thousand global addresses) and flushed once at the end of the workgroup's grid-stride loop.
+#define LH_MAX_COLS 8192
+
+template <int G, bool HAS_T2, bool LH>
 __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
     const i64* __restrict__ rowptrT1, const int32_t* __restrict__ colT1,
@@ -70,8 +75,13 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
   constexpr int GPB = OCN_BLOCK / G;
   __shared__ int32_t s_t1[GPB][T1_CAP];
   __shared__ int32_t s_t2[GPB][OCN_WAVE];
+  extern __shared__ __attribute__((aligned(16))) u64 s_hist[];      // LH only: n_cols words
   const int gl = threadIdx.x % G, g = threadIdx.x / G;
   if (blockIdx.x == 0 && threadIdx.x == 0 && off[B] > cap) atomicOr(status, 1);
+  if (LH) {
+    for (i64 c = threadIdx.x; c < n_cols; c += OCN_BLOCK) s_hist[c] = 0ull;
+    __syncthreads();
+  }
   for (i64 e0 = (i64)blockIdx.x * GPB; e0 < B; e0 += (i64)gridDim.x * GPB) {
     const i64 slot = e0 + g;                  // processing slot; `order` maps it to a batch row
     const bool act = slot < B;
@@ -119,8 +129,10 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
       if (fits) flags[base + p] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
 #endif
 #ifndef OCN_X_NOATOMIC
-      if (f1 | f2)
-        atomicAdd(hist + 2 * (i64)k, (u64)f1 | ((u64)f2 << HF_BITS) | (1ull << (2 * HF_BITS)));
+      if (f1 | f2) {
+        const u64 inc = (u64)f1 | ((u64)f2 << HF_BITS) | (1ull << (2 * HF_BITS));
+        if (LH) atomicAdd(s_hist + k, inc); else atomicAdd(hist + 2 * (i64)k, inc);
+      }
 #endif
       c1 += f1;
       c2 += f2;
@@ -135,6 +147,12 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
       if (cnt2) cnt2[e] = c2;
     }
     __syncthreads();
+  }
+  if (LH) {
+    for (i64 c = threadIdx.x; c < n_cols; c += OCN_BLOCK) {
+      const u64 v = s_hist[c];
+      if (v) atomicAdd(hist + 2 * c, v);
+    }
   }
 }
 
@@ -652,18 +670,36 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
   if (!rowptrA || !rowptrT1 || !src || !dst || !off || !hist || !cnt1 || !status) return OCN_EINVAL;
   // col pointers may legitimately be NULL for an adjacency with no entries
   constexpr int GPB = OCN_BLOCK / OCN_X_G;
-  const int grid = grid_for((B + GPB - 1) / GPB);
   hipStream_t st = (hipStream_t)stream;
-  if (rowptrT2)
-    hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, true>), dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
-                       colA, (const i64*)rowptrT1, colT1, (const i64*)rowptrT2, colT2, (const i64*)src,
-                       (const i64*)dst, (const i64*)order, (i64)B, (i64)n_cols, (const i64*)off, flags,
-                       (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
-  else
-    hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, false>), dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA,
-                       colA, (const i64*)rowptrT1, colT1, (const i64*)nullptr, (const int32_t*)nullptr,
-                       (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, (i64)n_cols, (const i64*)off,
-                       flags, (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
+  const bool lh = n_cols > 0 && n_cols <= LH_MAX_COLS;
+  const size_t lds = lh ? (size_t)n_cols * sizeof(u64) : 0;
+  // LH: a persistent grid (a few workgroups per CU) so that each LDS histogram absorbs many edges
+  const int grid = lh ? grid_for((B + GPB - 1) / GPB, 256 * 3) : grid_for((B + GPB - 1) / GPB);
+  if (lh) {                                   // static (target rows) + dynamic (histogram) LDS can pass 64 KiB
+    static bool raised = false;
+    if (!raised) {
+      hipFuncSetAttribute((const void*)cn_flags_kernel<OCN_X_G, true, true>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, LH_MAX_COLS * (int)sizeof(u64));
+      hipFuncSetAttribute((const void*)cn_flags_kernel<OCN_X_G, false, true>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, LH_MAX_COLS * (int)sizeof(u64));
+      raised = true;
+    }
+  }
+#define CN_FLAGS_ARGS(T2P, T2C)                                                                      \
+  (const i64*)rowptrA, colA, (const i64*)rowptrT1, colT1, (const i64*)(T2P), (T2C), (const i64*)src,  \
+      (const i64*)dst, (const i64*)order, (i64)B, (i64)n_cols, (const i64*)off, flags, (i64)flags_cap, \
+      (u64*)hist, cnt1, cnt2, status
+  if (rowptrT2) {
+    if (lh) hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, true, true>), dim3(grid), dim3(OCN_BLOCK), lds, st,
+                               CN_FLAGS_ARGS(rowptrT2, colT2));
+    else hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, true, false>), dim3(grid), dim3(OCN_BLOCK), 0, st,
+                            CN_FLAGS_ARGS(rowptrT2, colT2));
+  } else {
+    if (lh) hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, false, true>), dim3(grid), dim3(OCN_BLOCK), lds, st,
+                               CN_FLAGS_ARGS(nullptr, (const int32_t*)nullptr));
+    else hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, false, false>), dim3(grid), dim3(OCN_BLOCK), 0, st,
+                            CN_FLAGS_ARGS(nullptr, (const int32_t*)nullptr));
+  }
   return launch_status();
 }
 
