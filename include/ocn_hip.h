@@ -135,19 +135,22 @@ int ocn_cn_gather_backward(const int64_t* rowptrA, const int32_t* colA,
 /* CSR SpMM of the encoders: torch_sparse spmm_add/mean/max (model.py:42-55), PyG GCNConv
  * propagate (model.py:58-68), pygho/torch COO @ dense (model.py:105-113).
  *   y[r] = post[r] * reduce_k( pre[r]^a * pre[k] * x[k] )  (+ self term)
- * pre/post may be NULL (= 1).  mode: 0 sum, 1 mean, 2 max.
+ * pre/post may be NULL (= 1).  val: per-entry values of a valued adjacency (DropAdj's 1/(1-p)
+ * rescale in training, model.py:198-229) or NULL (all 1).  mode: 0 sum, 1 mean, 2 max.
  * edge_scale: 0 -> entry weight is pre[k] applied to x[k] first (PureConv: n*x then A.);
  *             1 -> entry weight is fl(pre[r]*pre[k]) (GCNConv / PureConv2: normalised A).
  * self_mode: 0 none; 1 add the row's own term after the neighbours (PureConv gcn);
  *            2 insert it at its sorted column position (GCNConv fill_diag). */
-int ocn_spmm_csr(const int64_t* rowptr, const int32_t* col, int64_t n_rows,
+int ocn_spmm_csr(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows,
                  const float* x, int32_t F, const float* pre, const float* post,
                  int32_t mode, int32_t edge_scale, int32_t self_mode,
                  float* y, void* stream);
 
 /* out[r] = 1/sqrt(add + deg(r)) (0 where the argument is 0): rsqrt_(1+adj.sum(-1)) of
- * model.py:51,106 (add=1) and gcn_norm's deg^-1/2 (add=1 after fill_diag). */
-int ocn_deg_rsqrt(const int64_t* rowptr, int64_t n_rows, float add, float* out, void* stream);
+ * model.py:51,106 (add=1) and gcn_norm's deg^-1/2 (add=1 after fill_diag); deg = row length, or the
+ * row sum of `val` for a valued adjacency. */
+int ocn_deg_rsqrt(const int64_t* rowptr, const float* val, int64_t n_rows, float add, float* out,
+                  void* stream);
 
 /* Pattern of A*A (NeighborOverlap_large.py:68-74,112-119: spadj @ spadj, values dropped).
  * Two phases around a caller-side allocation: count -> ocn_scan_i32 -> fill.

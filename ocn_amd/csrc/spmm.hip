@@ -4,10 +4,18 @@
 // ---------------------------------------------------------------------------------------------
 // encoder SpMM
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(OCN_BLOCK) void deg_rsqrt_kernel(const i64* __restrict__ rowptr, i64 n,
+__global__ __launch_bounds__(OCN_BLOCK) void deg_rsqrt_kernel(const i64* __restrict__ rowptr,
+                                                              const float* __restrict__ val, i64 n,
                                                               float add, float* __restrict__ out) {
   for (i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (i64)gridDim.x * blockDim.x) {
-    const float d = add + (float)(rowptr[r + 1] - rowptr[r]);
+    float deg;
+    if (val) {                               // valued adjacency (DropAdj rescale): adj.sum(dim=-1)
+      deg = 0.f;
+      for (i64 p = rowptr[r]; p < rowptr[r + 1]; ++p) deg += val[p];
+    } else {
+      deg = (float)(rowptr[r + 1] - rowptr[r]);
+    }
+    const float d = add + deg;
     out[r] = d > 0.f ? 1.0f / sqrtf(d) : 0.f;
   }
 }
@@ -30,7 +38,7 @@ __device__ __forceinline__ void red4(float4& acc, float w, bool weighted, const 
 template <int LPE, int NV, int MODE>
 __global__ __launch_bounds__(OCN_BLOCK) void spmm_csr_kernel(
     const i64* __restrict__ rowptr, const int32_t* __restrict__ col, i64 n_rows,
-    const float* __restrict__ x, int F, const float* __restrict__ pre,
+    const float* __restrict__ val, const float* __restrict__ x, int F, const float* __restrict__ pre,
     const float* __restrict__ post, int edge_scale, int self_mode, float* __restrict__ y) {
   constexpr int GPW = OCN_WAVE / LPE;
   constexpr int UNR = 4;
@@ -42,8 +50,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void spmm_csr_kernel(
   const i64 a0 = rowptr[r], da = rowptr[r + 1] - a0;
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const i64 rowq = F >> 2;
-  const bool weighted = pre != nullptr;
-  const float pr = weighted ? pre[r] : 1.0f;
+  const bool weighted = pre != nullptr || val != nullptr;
+  const float pr = pre ? pre[r] : 1.0f;
 
   float4 acc[NV];
   const float init = MODE == SPMM_MAX ? -INFINITY : 0.f;
@@ -51,7 +59,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void spmm_csr_kernel(
   for (int v = 0; v < NV; ++v) acc[v] = make_float4(init, init, init, init);
 
   // the row's own term: weight pre[r] (edge_scale 0) or fl(pre[r]*pre[r]) (edge_scale 1)
-  const float wself = weighted ? (edge_scale ? __fmul_rn(pr, pr) : pr) : 1.0f;
+  const float wself = pre ? (edge_scale ? __fmul_rn(pr, pr) : pr) : 1.0f;
   bool self_done = self_mode != 2;
   i64 seen = 0;
 
@@ -61,7 +69,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void spmm_csr_kernel(
     float wk = 1.0f;
     if (p < da) {
       k = col[a0 + p];
-      if (weighted) wk = edge_scale ? __fmul_rn(pr, pre[k]) : pre[k];
+      if (pre) wk = edge_scale ? __fmul_rn(pr, pre[k]) : pre[k];
+      if (val) wk = __fmul_rn(val[a0 + p], wk);
     }
     const int cnt = (int)((da - p0) < LPE ? (da - p0) : LPE);
     for (int b0 = 0; b0 < cnt; b0 += UNR) {
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void spmm_csr_kernel(
 
 extern "C" {
 
-#define SPMM_ARGS (const i64*)rowptr, col, (i64)n_rows, x, (int)F, pre, post, (int)edge_scale, \
+#define SPMM_ARGS (const i64*)rowptr, col, (i64)n_rows, val, x, (int)F, pre, post, (int)edge_scale, \
                   (int)self_mode, y
 #define LAUNCH_SPMM(LPE, NV, MODE)                                                                  \
   do {                                                                                              \
@@ -141,7 +150,7 @@ extern "C" {
     else return OCN_EINVAL; /* feature widths of the reference configs only (16..512, pow2) */      \
   } while (0)
 
-int ocn_spmm_csr(const int64_t* rowptr, const int32_t* col, int64_t n_rows, const float* x,
+int ocn_spmm_csr(const int64_t* rowptr, const int32_t* col, const float* val, int64_t n_rows, const float* x,
                  int32_t F, const float* pre, const float* post, int32_t mode, int32_t edge_scale,
                  int32_t self_mode, float* y, void* stream) {
   if (n_rows < 0 || F <= 0 || mode < 0 || mode > 2 || self_mode < 0 || self_mode > 2) return OCN_EINVAL;
@@ -154,12 +163,13 @@ int ocn_spmm_csr(const int64_t* rowptr, const int32_t* col, int64_t n_rows, cons
   return launch_status();
 }
 
-int ocn_deg_rsqrt(const int64_t* rowptr, int64_t n_rows, float add, float* out, void* stream) {
+int ocn_deg_rsqrt(const int64_t* rowptr, const float* val, int64_t n_rows, float add, float* out,
+                  void* stream) {
   if (n_rows < 0 || (n_rows > 0 && (!rowptr || !out))) return OCN_EINVAL;
   if (n_rows == 0) return 0;
   const int grid = grid_for((n_rows + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
   hipLaunchKernelGGL(deg_rsqrt_kernel, dim3(grid), dim3(OCN_BLOCK), 0, (hipStream_t)stream,
-                     (const i64*)rowptr, (i64)n_rows, add, out);
+                     (const i64*)rowptr, val, (i64)n_rows, add, out);
   return launch_status();
 }
 

@@ -65,13 +65,14 @@ class DropAdj(nn.Module):
 class _SpmmFn(torch.autograd.Function):
     """y = M x for one of the encoder operators.  The drivers' adjacencies are symmetric
     (``to_symmetric``, NeighborOverlap_large.py:63, ogbdataset.py:45), and so are A, P(A+I)P and
-    D^-½(A+I)D^-½: the backward is the same kernel applied to the gradient.  ``mean`` (D⁻¹A) has the
-    transpose A D⁻¹; ``max`` is not differentiated here."""
+    D^-½(A+I)D^-½: the backward is the same kernel applied to the gradient.  A valued adjacency
+    (DropAdj masks directed entries, so it is no longer symmetric) uses its transpose.  ``mean``
+    (D⁻¹A) has the transpose A D⁻¹; ``max`` is not differentiated here."""
 
     @staticmethod
     def forward(ctx, x, adj, kw):
         ctx.adj, ctx.kw = adj, kw
-        return ops.spmm_csr(adj._rowptr, adj._col, x, **kw)
+        return ops.spmm_csr(adj._rowptr, adj._col, x, val=adj._value, **kw)
 
     @staticmethod
     def backward(ctx, g):
@@ -80,16 +81,20 @@ class _SpmmFn(torch.autograd.Function):
         mode = kw.get("mode", "sum")
         if mode == "max":
             raise NotImplementedError("backward of max aggregation")
+        if adj._value is not None:
+            adj = adj.t()
+            if mode == "mean":
+                raise NotImplementedError("backward of mean aggregation over a valued adjacency")
         if mode == "mean":
             deg = (adj._rowptr[1:] - adj._rowptr[:-1]).clamp(min=1).to(torch.float32)
             return ops.spmm_csr(adj._rowptr, adj._col, g, pre=1.0 / deg, mode="sum"), None, None
-        return ops.spmm_csr(adj._rowptr, adj._col, g, **kw), None, None
+        return ops.spmm_csr(adj._rowptr, adj._col, g, val=adj._value, **kw), None, None
 
 
 def _spmm(adj: SparseTensor, x: Tensor, **kw) -> Tensor:
     if torch.is_grad_enabled() and x.requires_grad:
         return _SpmmFn.apply(x, adj, kw)
-    return ops.spmm_csr(adj._rowptr, adj._col, x, **kw)
+    return ops.spmm_csr(adj._rowptr, adj._col, x, val=adj._value, **kw)
 
 
 class _PoolFn(torch.autograd.Function):
@@ -111,10 +116,10 @@ class _PoolFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------
 # message passing layers
 # ------------------------------------------------------------------------------------------
-def _no_values(adj: SparseTensor, who: str) -> None:
-    if adj.has_value():
-        raise NotImplementedError(f"{who}: valued adjacencies (train-time DropAdj rescale) are not on "
-                                  "the forward-only path")
+def _values(adj: SparseTensor):
+    """fp32 entry values of a valued adjacency (DropAdj's rescale in training) or None."""
+    v = adj._value
+    return None if v is None else v.to(torch.float32)
 
 
 class PureConv(nn.Module):
@@ -131,11 +136,10 @@ class PureConv(nn.Module):
 
     def forward(self, x, adj_t: SparseTensor):
         x = self.lin(x).contiguous()
-        _no_values(adj_t, "PureConv")
         if self.aggr in ("mean", "max", "sum"):
             return _spmm(adj_t, x, mode=self.aggr)
         if self.aggr == "gcn":
-            norm = ops.deg_rsqrt(adj_t._rowptr, 1.0)
+            norm = ops.deg_rsqrt(adj_t._rowptr, 1.0, val=_values(adj_t))
             return _spmm(adj_t, x, pre=norm, post=norm, mode="sum", edge_scale=False, self_mode=1)
         raise ValueError(self.aggr)
 
@@ -156,10 +160,9 @@ class GCNConv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
 
     def forward(self, x, adj_t: SparseTensor):
-        _no_values(adj_t, "GCNConv")
         x = self.lin(x).contiguous()
         if self.normalize:
-            dinv = ops.deg_rsqrt(adj_t._rowptr, 1.0)        # degree of A + I (A has no self loops)
+            dinv = ops.deg_rsqrt(adj_t._rowptr, 1.0, val=_values(adj_t))   # degree of A + I (A has no self loops)
             out = _spmm(adj_t, x, pre=dinv, mode="sum", edge_scale=True,
                         self_mode=2 if self.add_self_loops else 0)
         else:
@@ -198,12 +201,11 @@ class PureConv2(nn.Module):
             self.lin = nn.Sequential(nn.Linear(indim, outdim, bias=False), nn.ReLU(inplace=True))
 
     def forward(self, x, adj_t: SparseTensor):
-        _no_values(adj_t, "PureConv2")
         x = x.contiguous()
         if self.aggr in ("mean", "max", "sum"):
             x = _spmm(adj_t, x, mode=self.aggr)
         elif self.aggr == "gcn":
-            norm = ops.deg_rsqrt(adj_t._rowptr, 1.0)
+            norm = ops.deg_rsqrt(adj_t._rowptr, 1.0, val=_values(adj_t))
             x = _spmm(adj_t, x, pre=norm, mode="sum", edge_scale=True)
         return self.lin(x)
 

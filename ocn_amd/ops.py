@@ -195,7 +195,7 @@ SPMM_MODES = {"sum": 0, "add": 0, "mean": 1, "max": 2}
 
 def spmm_csr(rowptr: Tensor, col: Tensor, x: Tensor, pre: Optional[Tensor] = None,
              post: Optional[Tensor] = None, mode: str = "sum", edge_scale: bool = False,
-             self_mode: int = 0) -> Tensor:
+             self_mode: int = 0, val: Optional[Tensor] = None) -> Tensor:
     _req(rowptr, torch.int64, "rowptr", 1); _req(col, torch.int32, "col", 1)
     _req(x, torch.float32, "x", 2)
     n = rowptr.numel() - 1
@@ -205,18 +205,20 @@ def spmm_csr(rowptr: Tensor, col: Tensor, x: Tensor, pre: Optional[Tensor] = Non
         raise ValueError("post must have one entry per output row")
     if self_mode and x.shape[0] != n:
         raise ValueError("self term needs a square operator")
+    if val is not None and _req(val, torch.float32, "val", 1).numel() != col.numel():
+        raise ValueError("val must have one entry per stored column")
     y = torch.empty(n, x.shape[1], dtype=torch.float32, device=x.device)
-    check(_lib.lib().ocn_spmm_csr(ptr(rowptr), ptr(col), n, ptr(x), x.shape[1], ptr(pre), ptr(post),
+    check(_lib.lib().ocn_spmm_csr(ptr(rowptr), ptr(col), ptr(val), n, ptr(x), x.shape[1], ptr(pre), ptr(post),
                                   SPMM_MODES[mode], int(edge_scale), int(self_mode), ptr(y), stream_ptr()),
           "ocn_spmm_csr")
     return y
 
 
-def deg_rsqrt(rowptr: Tensor, add: float = 1.0) -> Tensor:
+def deg_rsqrt(rowptr: Tensor, add: float = 1.0, val: Optional[Tensor] = None) -> Tensor:
     _req(rowptr, torch.int64, "rowptr", 1)
     n = rowptr.numel() - 1
     out = torch.empty(n, dtype=torch.float32, device=rowptr.device)
-    check(_lib.lib().ocn_deg_rsqrt(ptr(rowptr), n, float(add), ptr(out), stream_ptr()), "ocn_deg_rsqrt")
+    check(_lib.lib().ocn_deg_rsqrt(ptr(rowptr), ptr(val), n, float(add), ptr(out), stream_ptr()), "ocn_deg_rsqrt")
     return out
 
 

@@ -199,6 +199,15 @@ class SparseTensor:
         return SparseTensor(row=torch.cat([r, c]), col=torch.cat([c, r]), value=v,
                             sparse_sizes=self._sizes, trust_data=True).coalesce(reduce)
 
+    def t(self) -> "SparseTensor":
+        """Transpose (cached): CSR of Aᵀ with the values carried along — the operator of the SpMM
+        backward when the adjacency is not symmetric (DropAdj masks directed entries)."""
+        if getattr(self, "_t_cache", None) is None:
+            r, c = self._row64(), self._col.to(torch.int64)
+            self._t_cache = SparseTensor(row=c, col=r, value=self._value, sparse_sizes=(self._sizes[1], self._sizes[0]),
+                                         trust_data=True)
+        return self._t_cache
+
     def __getitem__(self, idx: Tensor) -> "SparseTensor":
         """Row select (utils.py:256-257): row e of the result is row idx[e]."""
         idx = idx.to(torch.int64)

@@ -101,10 +101,20 @@ class CNState:
     def cn5_batch_innerprod(self) -> Tensor:
         """Σ (cn2 ⊙ ncn1) of this batch (model.py:2241-2244), from the integer column counts:
         every entry in both sets contributes 1/S1 of its column.  Pattern route only."""
-        if self.walk:
-            raise NotImplementedError("running inner product of the walk-count route (training of the ppa / "
-                                      "citation2 drivers) is not built yet")
         hc = self.hist_counts()
+        if self.walk:
+            # valued cn2: Σ over entries in both sets of walk count / S1[col] (host-side format code,
+            # training only — the eval path never needs it)
+            n1 = hc[:, 0]
+            inv1 = torch.where(n1 >= 2, 1.0 / n1.clamp(min=1).to(torch.float32), torch.zeros((), device=n1.device))
+            both = self.materialize(1)
+            r, c, _ = both.coo()
+            cn2 = self.materialize(2)
+            key2 = cn2.coo()[0] * self.N + cn2.coo()[1]
+            key1 = r * self.N + c
+            idx = torch.searchsorted(key2, key1).clamp(max=max(key2.numel() - 1, 0))
+            hit = (key2[idx] == key1) if key2.numel() else torch.zeros_like(key1, dtype=torch.bool)
+            return (cn2.storage.value()[idx[hit]] * inv1[c[hit]]).sum()
         n1 = hc[:, 0]
         nb = n1 + hc[:, 1] - hc[:, 2]
         inv1 = torch.where(n1 >= 2, 1.0 / n1.clamp(min=1).to(torch.float32), torch.zeros((), device=n1.device))

@@ -530,3 +530,67 @@ def test_cn5_scores_with_trained_innerprod(case, ip):
         out = pred.to(DEV)(x.to(DEV), case.adj, adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e), e)
     err = (out.cpu() - ref).abs().max().item()
     assert err <= 1e-5 + 1e-5 * ref.abs().max().item(), err
+
+
+# ---- valued, non-symmetric adjacencies (what DropAdj hands the encoder in training) -----------
+@pytest.mark.parametrize("kind", ["puregcn", "gcnconv", "pureconv2", "sum"])
+def test_valued_spmm_forward_and_transpose_backward(hiplib, kind):
+    from ocn_amd import ops
+    from ocn_amd.model import _spmm
+    from ocn_amd.sparse import SparseTensor
+    torch.manual_seed(4)
+    n, F = 300, 32
+    dense = (torch.rand(n, n) < 0.04).float() * (1.0 + torch.rand(n, n))      # valued, not symmetric
+    dense.fill_diagonal_(0)
+    r, c = dense.nonzero(as_tuple=True)
+    adj = SparseTensor(row=r.to(DEV), col=c.to(DEV), value=dense[r, c].to(DEV), sparse_sizes=(n, n))
+    x = torch.randn(n, F)
+    xr = x.clone().requires_grad_(True)
+    deg = dense.sum(1)
+    nrm = torch.rsqrt(1 + deg)
+    if kind == "puregcn":                                   # model.py:50-55 with a valued adj_t
+        xs = nrm[:, None] * xr
+        ref = nrm[:, None] * (dense @ xs + xs)
+        kw = dict(pre="n", post="n", mode="sum", edge_scale=False, self_mode=1)
+    elif kind == "gcnconv":                                 # D^-1/2 (A_w + I) D^-1/2
+        a = dense + torch.eye(n)
+        ref = (nrm[:, None] * a * nrm[None, :]) @ xr
+        kw = dict(pre="n", mode="sum", edge_scale=True, self_mode=2)
+    elif kind == "pureconv2":                               # (A_w ⊙ n nᵀ) x, no self term
+        ref = (nrm[:, None] * dense * nrm[None, :]) @ xr
+        kw = dict(pre="n", mode="sum", edge_scale=True)
+    else:
+        ref = dense @ xr
+        kw = dict(mode="sum")
+    nd = ops.deg_rsqrt(adj._rowptr, 1.0, val=adj._value)
+    assert torch.allclose(nd.cpu(), nrm, atol=1e-6, rtol=1e-6)
+    kw = {k: (nd if v == "n" else v) for k, v in kw.items()}
+    w = torch.randn(n, F, generator=torch.Generator().manual_seed(1))
+    (ref * w).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    out = _spmm(adj, xd, **kw)
+    assert torch.allclose(out.cpu(), ref.detach(), atol=2e-5, rtol=2e-5)
+    (out * w.to(DEV)).sum().backward()
+    assert torch.allclose(xd.grad.cpu(), xr.grad, atol=2e-5, rtol=2e-5), (xd.grad.cpu() - xr.grad).abs().max()
+
+
+def test_encoder_trains_through_dropadj(hiplib):
+    import ocn_amd.model as M
+    oadj = make_graph(400, 8, 60, 41)
+    adj = to_product(oadj, DEV)
+    torch.manual_seed(0)
+    enc = M.GCN(32, 64, 64, 3, 0.1, False, True, 400, "puregcn", False, 0.5, taildropout=0.2).to(DEV).train()   # ddi-like
+    out = enc(torch.arange(400, device=DEV), adj)
+    out.square().mean().backward()
+    g = enc.xemb[0].weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max().item() > 0
+
+
+def test_walk_route_training_innerprod(case):
+    from ocn_amd.utils import CNState
+    oc1, oc2 = O.get_cn1_cn2(case.oadj, case.e)
+    ref = O.cn5_batch_innerprod(oc1, oc2).item()
+    st = CNState(case.adj, None, None, case.e.to(DEV), walk=True)
+    assert st.cn5_batch_innerprod().item() == pytest.approx(ref, rel=1e-5, abs=1e-5)
+    st2 = CNState(case.adj, case.adj, case.adj2, case.e.to(DEV))
+    assert st2.cn5_batch_innerprod().item() == pytest.approx(O.cn5_batch_innerprod(case.ocn1, case.ocn2).item(), rel=1e-5, abs=1e-5)
