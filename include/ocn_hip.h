@@ -66,6 +66,8 @@ int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, vo
  * histograms are accumulated (cn.sum(dim=0), model.py:2261,3114): hist[k] = {packed, walks}
  * with packed = n1 | n2 << 21 | n_union << 42 (one 64-bit atomic per CN entry) and walks = 0
  * here; must be zero on entry; B < 2^21.  T2 may be NULL (single adjoverlap call).
+ * bitmapT2: optional dense bit rows of T2 (row j at bitmapT2 + j*bm_stride_words, bit k = column k;
+ * written by ocn_spgemm_pattern_count): membership in the long A² row becomes one probe.
  * status: device int32, bit 0 set if off[B] > flags_cap (nothing is written past the cap).
  * order (here and below): optional permutation of 0..B-1 giving the order in which the batch rows
  * are PROCESSED (e.g. sorted by src so that rows sharing neighbourhoods meet in L2); every output
@@ -73,6 +75,7 @@ int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, vo
 int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA,
                  const int64_t* rowptrT1, const int32_t* colT1,
                  const int64_t* rowptrT2, const int32_t* colT2,
+                 const uint32_t* bitmapT2 /* or NULL */, int64_t bm_stride_words,
                  const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                  int64_t n_cols, const int64_t* off, uint8_t* flags, int64_t flags_cap,
                  uint64_t* hist /* [n_cols][2] */, int32_t* cnt1, int32_t* cnt2,
@@ -153,12 +156,15 @@ int ocn_deg_rsqrt(const int64_t* rowptr, const float* val, int64_t n_rows, float
                   void* stream);
 
 /* Pattern of A*A (NeighborOverlap_large.py:68-74,112-119: spadj @ spadj, values dropped).
- * Two phases around a caller-side allocation: count -> ocn_scan_i32 -> fill.
+ * Two phases around a caller-side allocation: count -> ocn_scan_i32 -> fill.  The count phase can
+ * also leave every output row as a dense bit row (288 GB of HBM make N*N/8 bytes affordable up to a
+ * few hundred thousand nodes), which ocn_cn_flags then probes instead of searching the CSR row.
  * Needs n_cols <= ocn_spgemm_max_cols().  Output columns ascending per row. */
 int64_t ocn_spgemm_max_cols(void);
 int ocn_spgemm_pattern_count(const int64_t* rowptrA, const int32_t* colA, int64_t n_rows,
                              const int64_t* rowptrB, const int32_t* colB, int64_t n_colsB,
-                             int32_t* row_count, void* stream);
+                             int32_t* row_count, uint32_t* bitmap /* or NULL: [n_rows][bm_stride_words] */,
+                             int64_t bm_stride_words, void* stream);
 int ocn_spgemm_pattern_fill(const int64_t* rowptrA, const int32_t* colA, int64_t n_rows,
                             const int64_t* rowptrB, const int32_t* colB, int64_t n_colsB,
                             const int64_t* rowptrC, int32_t* colC, void* stream);

@@ -26,8 +26,8 @@ SIGNATURES = {
     "ocn_scan_i32": (c_int32, [_P, c_int64, _P, _P, _P]),
     "ocn_order_workspace_bytes": (c_int64, [c_int64]),
     "ocn_order_by_node": (c_int32, [_P, c_int64, c_int64, _P, _P, _P]),
-    "ocn_cn_flags": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, _P, _P, c_int64, _P, _P, _P, _P,
-                               _P]),
+    "ocn_cn_flags": (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int64, c_int64, _P, _P, c_int64, _P,
+                               _P, _P, _P, _P]),
     "ocn_chunk_offsets": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P, _P]),
     "ocn_walk_chunk": (c_int32, []),
     "ocn_cn_walk_flags": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
@@ -38,7 +38,7 @@ SIGNATURES = {
     "ocn_spmm_csr": (c_int32, [_P, _P, _P, c_int64, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "ocn_deg_rsqrt": (c_int32, [_P, _P, c_int64, c_float, _P, _P]),
     "ocn_spgemm_max_cols": (c_int64, []),
-    "ocn_spgemm_pattern_count": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P]),
+    "ocn_spgemm_pattern_count": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P]),
     "ocn_spgemm_pattern_fill": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, _P]),
     "ocn_rows_ln_relu": (c_int32, [_P, _P, _P, c_float, c_int32, c_int64, c_int32, _P, _P]),
     "ocn_combine3": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P]),

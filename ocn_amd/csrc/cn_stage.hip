@@ -68,6 +68,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
     const i64* __restrict__ rowptrT1, const int32_t* __restrict__ colT1,
     const i64* __restrict__ rowptrT2, const int32_t* __restrict__ colT2,
+    const unsigned* __restrict__ bmT2, i64 bm_stride,
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     i64 n_cols, const i64* __restrict__ off, uint8_t* __restrict__ flags, i64 cap,
     u64* __restrict__ hist, int32_t* __restrict__ cnt1, int32_t* __restrict__ cnt2,
@@ -87,19 +88,23 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     const bool act = slot < B;
     const i64 e = act ? (order ? order[slot] : slot) : 0;
     i64 a0 = 0, da = 0, b0 = 0, db = 0, c0 = 0, dc = 0, base = 0;
+    const unsigned* bm_row = nullptr;         // bit row of dst in T2, when T2 comes with a dense bitmap
     if (act) {
       const i64 i = src[e], j = dst[e];
       a0 = rowptrA[i]; da = rowptrA[i + 1] - a0;
       b0 = rowptrT1[j]; db = rowptrT1[j + 1] - b0;
-      if (HAS_T2) { c0 = rowptrT2[j]; dc = rowptrT2[j + 1] - c0; }
+      if (HAS_T2) {
+        if (bmT2) bm_row = bmT2 + j * bm_stride;
+        else { c0 = rowptrT2[j]; dc = rowptrT2[j + 1] - c0; }
+      }
       base = off[e];
     }
     // stage the short target row, and a 64-point sample of the long one, in this group's LDS slice
     const bool t1_lds = db <= T1_CAP;
     if (t1_lds)
       for (i64 q = gl; q < db; q += G) s_t1[g][q] = colT1[b0 + q];
-    const bool t2_full = HAS_T2 && dc == n_cols;        // a full row (dense A², e.g. ddi) contains every column
-    if (HAS_T2 && !t2_full) {
+    const bool t2_full = HAS_T2 && !bmT2 && dc == n_cols;   // a full row (dense A², e.g. ddi) contains every column
+    if (HAS_T2 && !t2_full && !bmT2) {
       if (dc > OCN_WAVE) {
 #pragma unroll
         for (int q = gl; q < OCN_WAVE; q += G) s_t2[g][q] = colT2[c0 + (((i64)q * dc) >> 6)];
@@ -121,9 +126,11 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
 #ifdef OCN_X_NOT2
       f2 = (k & 1) == 0;
 #else
-      if (HAS_T2)
-        f2 = t2_full ? true
-                     : (dc > OCN_WAVE ? sampled_has(&s_t2[g][0], colT2 + c0, dc, k) : sorted_has(&s_t2[g][0], dc, k));
+      if (HAS_T2) {
+        if (bmT2) f2 = (bm_row[k >> 5] >> (k & 31)) & 1u;    // one probe
+        else f2 = t2_full ? true
+                          : (dc > OCN_WAVE ? sampled_has(&s_t2[g][0], colT2 + c0, dc, k) : sorted_has(&s_t2[g][0], dc, k));
+      }
 #endif
 #ifndef OCN_X_NOFLAGS
       if (fits) flags[base + p] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
@@ -662,6 +669,7 @@ extern "C" {
 
 int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* rowptrT1,
                  const int32_t* colT1, const int64_t* rowptrT2, const int32_t* colT2,
+                 const uint32_t* bitmapT2, int64_t bm_stride_words,
                  const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                  int64_t n_cols, const int64_t* off, uint8_t* flags, int64_t flags_cap, uint64_t* hist,
                  int32_t* cnt1, int32_t* cnt2, int32_t* status, void* stream) {
@@ -686,7 +694,8 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
     }
   }
 #define CN_FLAGS_ARGS(T2P, T2C)                                                                      \
-  (const i64*)rowptrA, colA, (const i64*)rowptrT1, colT1, (const i64*)(T2P), (T2C), (const i64*)src,  \
+  (const i64*)rowptrA, colA, (const i64*)rowptrT1, colT1, (const i64*)(T2P), (T2C),                   \
+      (const unsigned*)bitmapT2, (i64)bm_stride_words, (const i64*)src,                                \
       (const i64*)dst, (const i64*)order, (i64)B, (i64)n_cols, (const i64*)off, flags, (i64)flags_cap, \
       (u64*)hist, cnt1, cnt2, status
   if (rowptrT2) {

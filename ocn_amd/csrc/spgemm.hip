@@ -10,7 +10,8 @@ template <bool FILL>
 __global__ __launch_bounds__(OCN_BLOCK) void spgemm_pattern_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA, i64 n_rows,
     const i64* __restrict__ rowptrB, const int32_t* __restrict__ colB, i64 n_colsB,
-    int32_t* __restrict__ row_count, const i64* __restrict__ rowptrC, int32_t* __restrict__ colC) {
+    int32_t* __restrict__ row_count, const i64* __restrict__ rowptrC, int32_t* __restrict__ colC,
+    unsigned* __restrict__ bitmap_out, i64 bm_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned bm[];
   __shared__ i64 sh[2 * OCN_WPB];
   const int words = (int)((n_colsB + 31) >> 5);
@@ -37,6 +38,10 @@ __global__ __launch_bounds__(OCN_BLOCK) void spgemm_pattern_kernel(
     i64 ex = block_excl_scan(c, sh, &tot);
     if (!FILL) {
       if (threadIdx.x == 0) row_count[r] = (int32_t)tot;
+      if (bitmap_out) {                       // the row as a dense bit row: one probe answers k in row r
+        for (int w = threadIdx.x; w < words; w += OCN_BLOCK) bitmap_out[r * bm_stride + w] = bm[w];
+        __syncthreads();
+      }
       for (int w = w0; w < w1; ++w) bm[w] = 0u;
     } else {
       int32_t* out = colC + rowptrC[r] + ex;
@@ -60,7 +65,8 @@ int64_t ocn_spgemm_max_cols(void) { return (int64_t)SPGEMM_MAX_LDS * 8; }
 
 static int spgemm_launch(bool fill, const int64_t* rowptrA, const int32_t* colA, int64_t n_rows,
                          const int64_t* rowptrB, const int32_t* colB, int64_t n_colsB,
-                         int32_t* row_count, const int64_t* rowptrC, int32_t* colC, void* stream) {
+                         int32_t* row_count, const int64_t* rowptrC, int32_t* colC, uint32_t* bitmap,
+                         int64_t bm_stride, void* stream) {
   if (n_rows < 0 || n_colsB <= 0 || n_colsB > ocn_spgemm_max_cols()) return OCN_EINVAL;
   if (n_rows == 0) return 0;
   if (!rowptrA || !rowptrB) return OCN_EINVAL;
@@ -76,24 +82,25 @@ static int spgemm_launch(bool fill, const int64_t* rowptrA, const int32_t* colA,
     if (err != hipSuccess) return (int)err;
     hipLaunchKernelGGL(spgemm_pattern_kernel<true>, dim3(grid), dim3(OCN_BLOCK), lds, st,
                        (const i64*)rowptrA, colA, (i64)n_rows, (const i64*)rowptrB, colB, (i64)n_colsB,
-                       row_count, (const i64*)rowptrC, colC);
+                       row_count, (const i64*)rowptrC, colC, (unsigned*)nullptr, (i64)0);
   } else {
     err = hipFuncSetAttribute((const void*)spgemm_pattern_kernel<false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (err != hipSuccess) return (int)err;
     hipLaunchKernelGGL(spgemm_pattern_kernel<false>, dim3(grid), dim3(OCN_BLOCK), lds, st,
                        (const i64*)rowptrA, colA, (i64)n_rows, (const i64*)rowptrB, colB, (i64)n_colsB,
-                       row_count, (const i64*)rowptrC, colC);
+                       row_count, (const i64*)rowptrC, colC, (unsigned*)bitmap, (i64)bm_stride);
   }
   return launch_status();
 }
 
 int ocn_spgemm_pattern_count(const int64_t* rowptrA, const int32_t* colA, int64_t n_rows,
                              const int64_t* rowptrB, const int32_t* colB, int64_t n_colsB,
-                             int32_t* row_count, void* stream) {
+                             int32_t* row_count, uint32_t* bitmap, int64_t bm_stride_words, void* stream) {
   if (!row_count && n_rows > 0) return OCN_EINVAL;
+  if (bitmap && bm_stride_words < (n_colsB + 31) / 32) return OCN_EINVAL;
   return spgemm_launch(false, rowptrA, colA, n_rows, rowptrB, colB, n_colsB, row_count, nullptr,
-                       nullptr, stream);
+                       nullptr, bitmap, bm_stride_words, stream);
 }
 
 int ocn_spgemm_pattern_fill(const int64_t* rowptrA, const int32_t* colA, int64_t n_rows,
@@ -101,7 +108,7 @@ int ocn_spgemm_pattern_fill(const int64_t* rowptrA, const int32_t* colA, int64_t
                             const int64_t* rowptrC, int32_t* colC, void* stream) {
   if ((!rowptrC || !colC) && n_rows > 0) return OCN_EINVAL;
   return spgemm_launch(true, rowptrA, colA, n_rows, rowptrB, colB, n_colsB, nullptr, rowptrC, colC,
-                       stream);
+                       nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -17,6 +17,7 @@ FLAGS_NOSYNC_LIMIT = 1 << 30     # bytes of flag buffer we are willing to over-a
 validate_indices = True          # bounds-check candidate edges on the host side (one sync per batch)
 stage_timer = None               # optional object with .mark(name): bench.py records HIP events between stages
 LN_WIDTHS = (16, 32, 64, 128, 256, 512)   # row widths of the lane-group kernels (LayerNorm, pooling backward)
+a2_bitmap_max_bytes = 16 << 30   # keep A·B also as dense bit rows when n_rows * n_cols / 8 fits this budget
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 
 
@@ -85,7 +86,7 @@ def hist_counts(hist: Tensor) -> Tensor:
 
 def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
              t2: Optional[Tuple[Tensor, Tensor]], src: Tensor, dst: Tensor, n_cols: int, max_deg_a: int,
-             walk: bool = False):
+             walk: bool = False, t2_bitmap: Optional[Tensor] = None):
     """Intersection pass.  ``walk=False``: flags of N(src) against the rows of dst in t1 (and t2).
     ``walk=True``: the pygho route on A itself (t1/t2 ignored): cn1 flags + walk counts.
     Returns (order|None, off, flags, wc|None, hist[N,2] int64 packed, cnt1, cnt2|None, status)."""
@@ -132,8 +133,13 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
                                            ptr(wc), cap, ptr(hist), ptr(cnt1), ptr(cnt2), ptr(status),
                                            stream_ptr()), "ocn_cn_walk_flags")
     else:
+        if t2_bitmap is not None:
+            _req(t2_bitmap, torch.int32, "t2_bitmap", 2)
+            if t2 is None or t2_bitmap.shape[0] != t2[0].numel() - 1 or t2_bitmap.shape[1] * 32 < n_cols:
+                raise ValueError("t2_bitmap does not match the T2 adjacency")
         check(_lib.lib().ocn_cn_flags(ptr(rowptrA), ptr(colA), ptr(t1[0]), ptr(t1[1]),
                                       ptr(t2[0] if t2 else None), ptr(t2[1] if t2 else None),
+                                      ptr(t2_bitmap), t2_bitmap.shape[1] if t2_bitmap is not None else 0,
                                       ptr(src), ptr(dst), ptr(order), B, n_cols, ptr(off), ptr(flags), cap, ptr(hist),
                                       ptr(cnt1), ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_flags")
     _mark("cn_flags")
@@ -223,7 +229,8 @@ def deg_rsqrt(rowptr: Tensor, add: float = 1.0, val: Optional[Tensor] = None) ->
 
 
 def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int):
-    """CSR pattern of A·B (columns ascending).  One host sync for the output size."""
+    """CSR pattern of A·B (columns ascending) and, when it fits ``a2_bitmap_max_bytes``, the same
+    rows as dense bit rows.  One host sync for the output size."""
     _req(rowptrA, torch.int64, "rowptrA", 1); _req(colA, torch.int32, "colA", 1)
     _req(rowptrB, torch.int64, "rowptrB", 1); _req(colB, torch.int32, "colB", 1)
     l = _lib.lib()
@@ -234,15 +241,19 @@ def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int):
     n = rowptrA.numel() - 1
     dev = colA.device
     cnt = torch.empty(n, dtype=torch.int32, device=dev)
+    words = (n_cols_b + 31) // 32
+    bitmap = None
+    if n * words * 4 <= a2_bitmap_max_bytes and n > 0:
+        bitmap = torch.empty(n, words, dtype=torch.int32, device=dev)       # every row is written in full
     check(l.ocn_spgemm_pattern_count(ptr(rowptrA), ptr(colA), n, ptr(rowptrB), ptr(colB), n_cols_b,
-                                     ptr(cnt), stream_ptr()), "ocn_spgemm_pattern_count")
+                                     ptr(cnt), ptr(bitmap), words, stream_ptr()), "ocn_spgemm_pattern_count")
     rowptrC = scan_i32(cnt)
     nnz = int(rowptrC[-1].item())
     colC = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
     if nnz:
         check(l.ocn_spgemm_pattern_fill(ptr(rowptrA), ptr(colA), n, ptr(rowptrB), ptr(colB), n_cols_b,
                                         ptr(rowptrC), ptr(colC), stream_ptr()), "ocn_spgemm_pattern_fill")
-    return rowptrC, colC
+    return rowptrC, colC, bitmap
 
 
 def rows_ln_relu(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu: bool, inplace: bool = False) -> Tensor:

@@ -75,6 +75,7 @@ class SparseTensor:
         self._value = None if value is None else value.contiguous()
         self._row_cache: Optional[Tensor] = None
         self._maxdeg: Optional[int] = None
+        self._bitmap: Optional[Tensor] = None
         self.storage = _Storage(self)
 
     # ---- constructors ------------------------------------------------------------------
@@ -258,9 +259,10 @@ class CooView:
         a, b = self.sp, other.sp
         if a._sizes[1] != b._sizes[0]:
             raise ValueError("shape mismatch in sparse @ sparse")
-        rowptr, col = ops.spgemm_pattern(a._rowptr, a._col, b._rowptr, b._col, b._sizes[1])
-        return CooView(SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(a._sizes[0], b._sizes[1])),
-                       is_product=True)
+        rowptr, col, bitmap = ops.spgemm_pattern(a._rowptr, a._col, b._rowptr, b._col, b._sizes[1])
+        out = SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(a._sizes[0], b._sizes[1]))
+        out._bitmap = bitmap                   # dense bit rows of the product, probed by the intersection kernel
+        return CooView(out, is_product=True)
 
     def to_torch(self) -> Tensor:
         sp = self.sp

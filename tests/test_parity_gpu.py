@@ -594,3 +594,24 @@ def test_walk_route_training_innerprod(case):
     assert st.cn5_batch_innerprod().item() == pytest.approx(ref, rel=1e-5, abs=1e-5)
     st2 = CNState(case.adj, case.adj, case.adj2, case.e.to(DEV))
     assert st2.cn5_batch_innerprod().item() == pytest.approx(O.cn5_batch_innerprod(case.ocn1, case.ocn2).item(), rel=1e-5, abs=1e-5)
+
+
+def test_bitmap_and_csr_search_of_adj2_agree(case):
+    """A² is probed through dense bit rows when they fit the budget, otherwise searched as a CSR row
+    (LDS sample + binary search): both must give the oracle's flags."""
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import CNState
+    assert case.adj2._bitmap is not None and case.adj2._bitmap.shape == (case.n, (case.n + 31) // 32)
+    plain = SparseTensor(rowptr=case.adj2._rowptr, col=case.adj2._col, sparse_sizes=case.adj2.sparse_sizes())
+    assert plain._bitmap is None
+    a = CNState(case.adj, case.adj, case.adj2, case.e.to(DEV))
+    b = CNState(case.adj, case.adj, plain, case.e.to(DEV))
+    assert torch.equal(a.cnt2, b.cnt2) and torch.equal(a.cnt1, b.cnt1)
+    assert torch.equal(a.hist, b.hist) and torch.equal(a.flags[: int(a.off[-1])], b.flags[: int(b.off[-1])])
+    assert b.cnt2.cpu().tolist() == torch.bincount(case.ocn2.row, minlength=case.B).tolist()
+    # the bit rows themselves: popcount per row == CSR row length
+    bits = case.adj2._bitmap.view(torch.uint8)
+    pop = torch.zeros(case.n, dtype=torch.int64, device=DEV)
+    for s in range(8):
+        pop += ((bits >> s) & 1).sum(dim=1)
+    assert torch.equal(pop, case.adj2.storage.rowcount())
