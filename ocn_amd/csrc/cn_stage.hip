@@ -686,10 +686,14 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
   if (lh) {                                   // static (target rows) + dynamic (histogram) LDS can pass 64 KiB
     static bool raised = false;
     if (!raised) {
-      hipFuncSetAttribute((const void*)cn_flags_kernel<OCN_X_G, true, true>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, LH_MAX_COLS * (int)sizeof(u64));
-      hipFuncSetAttribute((const void*)cn_flags_kernel<OCN_X_G, false, true>,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, LH_MAX_COLS * (int)sizeof(u64));
+      hipError_t e1 = hipFuncSetAttribute((const void*)cn_flags_kernel<OCN_X_G, true, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          LH_MAX_COLS * (int)sizeof(u64));
+      hipError_t e2 = hipFuncSetAttribute((const void*)cn_flags_kernel<OCN_X_G, false, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          LH_MAX_COLS * (int)sizeof(u64));
+      if (e1 != hipSuccess) return (int)e1;
+      if (e2 != hipSuccess) return (int)e2;
       raised = true;
     }
   }

@@ -262,6 +262,7 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
     if (z == 12345.678f) Y[0] = z;
     return; }
 #endif
+#ifdef OCN_X_LIN_DIRECTSTORE   /* timing experiment: 4-byte stores straight from the accumulator layout */
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const i64 row = row0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
@@ -271,6 +272,28 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
       for (int t = 0; t < NT; ++t) yr[32 * t] = acc[t][i];
     }
   }
+#else
+  // The accumulator layout gives each lane one column of 16 rows: 128 four-byte stores per lane.
+  // Instead each wave transposes 8 rows at a time through its slice of the (now idle) weight
+  // buffers and writes them back as whole rows, 16 bytes per lane, 1 KiB per wave-instruction.
+  float* tile = reinterpret_cast<float*>(&wbuf[0][0]) + w * (8 * N);     // 8 rows x N floats per wave
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) tile[(ii + 4 * hh) * N + 32 * t + r] = acc[t][4 * gq + ii];
+    __syncthreads();
+    const float4* t4 = reinterpret_cast<const float4*>(tile);
+#pragma unroll
+    for (int u = 0; u < (8 * N / 4) / OCN_WAVE; ++u) {
+      const int q = lane + OCN_WAVE * u;                     // float4 index inside the 8 x N slab
+      const i64 row = row0 + 8 * gq + q / (N / 4);
+      if (row < M) reinterpret_cast<float4*>(Y + row * N)[q % (N / 4)] = t4[q];
+    }
+    __syncthreads();
+  }
+#endif
 }
 
 extern "C" {

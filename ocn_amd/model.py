@@ -429,9 +429,28 @@ class _CNPredictorBase(nn.Module):
                 self.innerprod += beta * ip
         return self.innerprod
 
+    def train(self, mode: bool = True):
+        """Mode switches (the drivers call .train() / .eval() around every pass) also drop the cached
+        eval-path constants, so edits that bypass the version counters (``param.data``) cannot go stale
+        across a training pass."""
+        self._coef_key = None
+        for p in self.parameters():
+            ops._panels.pop(id(p), None)
+        return super().train(mode)
+
+    def _mix_coef(self) -> Tensor:
+        """[σ(α0), σ(α0)σ(α1), β] on the device, recomputed only when alpha / beta change
+        (their ``_version`` / storage): three tiny launches less per candidate batch."""
+        key = (self.alpha.data_ptr(), self.alpha._version, self.beta.data_ptr(), self.beta._version)
+        if getattr(self, "_coef_key", None) != key:
+            alpha = torch.sigmoid(self.alpha.detach()).cumprod(-1)
+            self._coef = torch.cat([alpha[:2], self.beta.detach()]).contiguous()
+            self._coef_key = key
+        return self._coef
+
     def _heads(self, x, xcn1, xcn2, xij):
-        alpha = torch.sigmoid(self.alpha).cumprod(-1)
         if self.training or torch.is_grad_enabled() or not xij.is_cuda or xij.shape[-1] % 4:
+            alpha = torch.sigmoid(self.alpha).cumprod(-1)
             xij = self.xijlin(xij)
             xcn1 = self.xcn1lin(xcn1)
             xcn2 = self.xcn2lin(xcn2)
@@ -442,7 +461,7 @@ class _CNPredictorBase(nn.Module):
         xij = _seq_eval(self.xijlin, xij)
         xcn1 = _seq_eval(self.xcn1lin, xcn1)
         xcn2 = _seq_eval(self.xcn2lin, xcn2)
-        z = ops.combine3(torch.cat([alpha[:2], self.beta]), xcn1, xcn2, xij)
+        z = ops.combine3(self._mix_coef(), xcn1, xcn2, xij)
         return _seq_eval(self.lin, z)
 
 

@@ -615,3 +615,30 @@ def test_bitmap_and_csr_search_of_adj2_agree(case):
     for s in range(8):
         pop += ((bits >> s) & 1).sum(dim=1)
     assert torch.equal(pop, case.adj2.storage.rowcount())
+
+
+def test_eval_caches_follow_parameter_updates(case):
+    """The eval fast path caches weight panels and mix coefficients; optimiser-style in-place updates
+    (version bump) and .data edits followed by a mode switch must both be seen."""
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    H = 32
+    torch.manual_seed(1)
+    x = torch.randn(case.n, H, device=DEV)
+    pred = predictor_dict["cn5"](H, H, 1, 3, 0.0, 0.0, True).to(DEV).eval()
+    e = case.e.to(DEV)
+
+    def run():
+        with torch.no_grad():
+            return pred(x, case.adj, adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e), e)
+
+    def run_modules():                       # autograd on -> plain torch modules, no caches involved
+        return pred(x, case.adj, adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e), e).detach()
+
+    assert close(run(), run_modules())
+    with torch.no_grad():
+        pred.alpha.add_(0.7); pred.beta.mul_(-2.0); pred.xcn1lin[0].weight.mul_(1.5); pred.lin[8].weight.add_(0.1)
+    assert close(run(), run_modules())
+    pred.xijlin[0].weight.data.mul_(0.5)     # bypasses the version counter ...
+    pred.train(); pred.eval()                # ... but every pass starts with a mode switch
+    assert close(run(), run_modules())
