@@ -482,7 +482,14 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
   const int lane = threadIdx.x & 63;
   const int gl = lane % LPE;
   const int gbase = lane - gl;
-  const i64 slot = ((i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
+  // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  The batch rows are
+  // visited in source-node order, so give every XCD one contiguous eighth of that order: rows
+  // with neighbouring sources then share an L2 instead of being spread over all eight.
+  i64 bid = blockIdx.x;
+#ifndef OCN_X_NOXCD
+  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+#endif
+  const i64 slot = (bid * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
   if (slot >= B) return;                    // whole group leaves together
   const i64 e = order ? order[slot] : slot;
   const i64 i = src[e], j = dst[e];
