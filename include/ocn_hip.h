@@ -188,11 +188,30 @@ int ocn_combine3(const float* coef, const float* x1, const float* x2, const floa
  * Epilogue, in this order: + bias (or NULL); LayerNorm over the N columns with gamma/beta/eps (or
  * both NULL); ReLU if relu != 0; then either store Y[M][N], or — when dotw != NULL — the trailing
  * Linear(N -> 1) of `lin`: Y[M] = <row, dotw> + dotb[0]. */
+typedef struct OcnLinearGroup {
+  const float* X; int64_t ldX;       /* input [M][K], row stride in floats (0 = K) */
+  int64_t M;
+  const void* Wp;                    /* panel of this group's weight */
+  const float* bias;                 /* or NULL */
+  const float* gamma; const float* beta; float eps;   /* LayerNorm, or both NULL */
+  int32_t relu;
+  const float* scale;                /* device float[1] multiplied in after ReLU, or NULL */
+  const float* addend; int64_t ldAdd;/* [M][N] added last (row stride, 0 = N), or NULL */
+  const float* dotw; const float* dotb;   /* trailing Linear(N -> 1): Y is [M]; or NULL */
+  float* Y; int64_t ldY;             /* output rows, row stride in floats (0 = N) */
+} OcnLinearGroup;
+
 int64_t ocn_linear_panel_bytes(int32_t N, int32_t K);
 int ocn_linear_split_weight(const float* W, int32_t N, int32_t K, void* Wp, void* stream);
 int ocn_linear_bf16x6(const float* X, int64_t M, int32_t K, const void* Wp, int32_t N,
                       const float* bias, const float* gamma, const float* beta, float eps,
                       int32_t relu, const float* dotw, const float* dotb, float* Y, void* stream);
+/* Up to 3 independent Linear layers of the same (K, N) in ONE launch (e.g. the first layers of
+ * xcn1lin, xcn2lin and xijlin): more workgroups than CU slots, so one group's LayerNorm epilogue
+ * overlaps another's MFMA loop, and strided outputs let two branches write the halves of a
+ * [M][2N] buffer that a K = 2N Linear then consumes (the branch mix of model.py:2436 folded into
+ * its weights).  `groups` is a HOST array. */
+int ocn_linear_grouped(const OcnLinearGroup* groups, int32_t n_groups, int32_t K, int32_t N, void* stream);
 
 #ifdef __cplusplus
 }

@@ -46,11 +46,20 @@ SIGNATURES = {
     "ocn_linear_split_weight": (c_int32, [_P, c_int32, c_int32, _P, _P]),
     "ocn_linear_bf16x6": (c_int32, [_P, c_int64, c_int32, _P, c_int32, _P, _P, _P, c_float, c_int32, _P, _P,
                                     _P, _P]),
+    "ocn_linear_grouped": (c_int32, [_P, c_int32, c_int32, c_int32, _P]),
 }
 
 
 class OcnHipError(RuntimeError):
     pass
+
+
+class OcnLinearGroup(ctypes.Structure):
+    """Mirror of ``OcnLinearGroup`` in include/ocn_hip.h."""
+    _fields_ = [("X", c_void_p), ("ldX", c_int64), ("M", c_int64), ("Wp", c_void_p), ("bias", c_void_p),
+                ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("relu", c_int32),
+                ("scale", c_void_p), ("addend", c_void_p), ("ldAdd", c_int64), ("dotw", c_void_p),
+                ("dotb", c_void_p), ("Y", c_void_p), ("ldY", c_int64)]
 
 
 def sources():

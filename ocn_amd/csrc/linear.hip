@@ -71,23 +71,48 @@ __global__ __launch_bounds__(OCN_BLOCK) void split_weight_kernel(const float* __
   }
 }
 
+// One launch can carry up to LIN_MAX_GROUPS independent Linear layers of the same (K, N): each
+// group has its own rows, weights and epilogue; workgroup tiles are numbered group after group.
+#define LIN_MAX_GROUPS 3
+struct LinGroup {
+  const float* X; i64 ldX; i64 M;            // input rows [M][K], row stride ldX floats
+  const __bf16* Wp;                          // pre-split weight panel
+  const float *bias, *gamma, *beta;          // + bias; LayerNorm (gamma/beta or both NULL)
+  const float* scale;                        // device scalar multiplied in after ReLU (or NULL)
+  const float* addend; i64 ldAdd;            // [M][N] tensor added last (or NULL)
+  const float *dotw, *dotb;                  // trailing Linear(N -> 1): Y becomes [M]
+  float* Y; i64 ldY;                         // output rows, row stride ldY floats
+  float eps; int relu; int tiles;            // tiles = ceil(M / LIN_ROWS)
+};
+struct LinArgs { int n_groups; int K; LinGroup g[LIN_MAX_GROUPS]; };
+
 template <int NT>
-__global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
-    const float* __restrict__ X, i64 M, int K, const __bf16* __restrict__ Wp,
-    const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float eps, int relu, const float* __restrict__ dotw, const float* __restrict__ dotb,
-    float* __restrict__ Y) {
+__global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(const LinArgs args) {
   constexpr int N = NT * 32;
   constexpr int PANEL = NT * 3 * 64;                      // bf16x8 fragments per k-step panel
   __shared__ __attribute__((aligned(16))) bf16x8 wbuf[2][PANEL];
   __shared__ float s_ep[4][N];                            // bias, gamma, beta, dotw: read once, up front
+  int tile = blockIdx.x, gi = 0;
+  while (gi + 1 < args.n_groups && tile >= args.g[gi].tiles) { tile -= args.g[gi].tiles; ++gi; }
+  const LinGroup& G = args.g[gi];
+  const float* __restrict__ X = G.X;
+  const i64 M = G.M;
+  const int K = args.K;
+  const float* __restrict__ bias = G.bias;
+  const float* __restrict__ gamma = G.gamma;
+  const float* __restrict__ beta = G.beta;
+  const float* __restrict__ dotw = G.dotw;
+  const float* __restrict__ dotb = G.dotb;
+  float* __restrict__ Y = G.Y;
+  const float eps = G.eps;
+  const int relu = G.relu;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const i64 row0 = (i64)blockIdx.x * LIN_ROWS + 32 * w;
+  const i64 row0 = (i64)tile * LIN_ROWS + 32 * w;
   i64 arow = row0 + r;
   if (arow >= M) arow = M - 1;                            // tail rows: load something valid, never store
-  const float4* xrow = reinterpret_cast<const float4*>(X + arow * K + 8 * hh);
-  const bf16x8* wp8 = reinterpret_cast<const bf16x8*>(Wp);
+  const float4* xrow = reinterpret_cast<const float4*>(X + arow * G.ldX + 8 * hh);
+  const bf16x8* wp8 = reinterpret_cast<const bf16x8*>(G.Wp);
   const int nks = K / LIN_KS;
 
   f32x16 acc[NT];
@@ -236,6 +261,13 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = fmaxf(acc[t][i], 0.f);
   }
+  if (G.scale) {
+    const float sc = G.scale[0];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] *= sc;
+  }
   if (dotw) {
     // trailing Linear(N -> 1): y[row] = <row, dotw> + dotb, one float per row
     float wv[NT];
@@ -267,29 +299,37 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(
   for (int i = 0; i < 16; ++i) {
     const i64 row = row0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
     if (row < M) {
-      float* yr = Y + row * N + r;
+      float* yr = Y + row * G.ldY + r;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) yr[32 * t] = acc[t][i];
+      for (int t = 0; t < NT; ++t)
+        yr[32 * t] = acc[t][i] + (G.addend ? G.addend[row * G.ldAdd + 32 * t + r] : 0.f);
     }
   }
 #else
   // The accumulator layout gives each lane one column of 16 rows: 128 four-byte stores per lane.
   // Instead each wave transposes 8 rows at a time through its slice of the (now idle) weight
   // buffers and writes them back as whole rows, 16 bytes per lane, 1 KiB per wave-instruction.
-  float* tile = reinterpret_cast<float*>(&wbuf[0][0]) + w * (8 * N);     // 8 rows x N floats per wave
+  float* slab = reinterpret_cast<float*>(&wbuf[0][0]) + w * (8 * N);     // 8 rows x N floats per wave
 #pragma unroll
   for (int gq = 0; gq < 4; ++gq) {
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) tile[(ii + 4 * hh) * N + 32 * t + r] = acc[t][4 * gq + ii];
+      for (int t = 0; t < NT; ++t) slab[(ii + 4 * hh) * N + 32 * t + r] = acc[t][4 * gq + ii];
     __syncthreads();
-    const float4* t4 = reinterpret_cast<const float4*>(tile);
+    const float4* t4 = reinterpret_cast<const float4*>(slab);
 #pragma unroll
     for (int u = 0; u < (8 * N / 4) / OCN_WAVE; ++u) {
       const int q = lane + OCN_WAVE * u;                     // float4 index inside the 8 x N slab
       const i64 row = row0 + 8 * gq + q / (N / 4);
-      if (row < M) reinterpret_cast<float4*>(Y + row * N)[q % (N / 4)] = t4[q];
+      if (row < M) {
+        float4 v = t4[q];
+        if (G.addend) {
+          const float4 ad = reinterpret_cast<const float4*>(G.addend + row * G.ldAdd)[q % (N / 4)];
+          v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+        }
+        reinterpret_cast<float4*>(Y + row * G.ldY)[q % (N / 4)] = v;
+      }
     }
     __syncthreads();
   }
@@ -308,25 +348,52 @@ int ocn_linear_split_weight(const float* W, int32_t N, int32_t K, void* Wp, void
   return launch_status();
 }
 
-#define LAUNCH_LINEAR(NT)                                                                           \
-  hipLaunchKernelGGL((linear_bf16x6_kernel<NT>), dim3((unsigned)((M + LIN_ROWS - 1) / LIN_ROWS)),   \
-                     dim3(OCN_BLOCK), 0, (hipStream_t)stream, X, (i64)M, (int)K, (const __bf16*)Wp, \
-                     bias, gamma, beta, eps, (int)relu, dotw, dotb, Y)
+static int launch_linear(const LinArgs& a, int N, hipStream_t st) {
+  int tiles = 0;
+  for (int g = 0; g < a.n_groups; ++g) tiles += a.g[g].tiles;
+  if (tiles == 0) return 0;
+  switch (N) {
+    case 32:  hipLaunchKernelGGL((linear_bf16x6_kernel<1>), dim3(tiles), dim3(OCN_BLOCK), 0, st, a); break;
+    case 64:  hipLaunchKernelGGL((linear_bf16x6_kernel<2>), dim3(tiles), dim3(OCN_BLOCK), 0, st, a); break;
+    case 128: hipLaunchKernelGGL((linear_bf16x6_kernel<4>), dim3(tiles), dim3(OCN_BLOCK), 0, st, a); break;
+    case 256: hipLaunchKernelGGL((linear_bf16x6_kernel<8>), dim3(tiles), dim3(OCN_BLOCK), 0, st, a); break;
+    default: return OCN_EINVAL;
+  }
+  return launch_status();
+}
+
+static int fill_group(LinGroup& g, const OcnLinearGroup& s, int K, int N) {
+  if (s.M < 0 || (s.M > 0 && (!s.X || !s.Wp || !s.Y))) return OCN_EINVAL;
+  if ((s.gamma == nullptr) != (s.beta == nullptr)) return OCN_EINVAL;
+  const int64_t ldX = s.ldX ? s.ldX : K, ldY = s.ldY ? s.ldY : (s.dotw ? 1 : N), ldA = s.ldAdd ? s.ldAdd : N;
+  if (ldX < K || (ldX & 3) || (!s.dotw && (ldY < N || (ldY & 3))) || (s.addend && (ldA < N || (ldA & 3)))) return OCN_EINVAL;
+  g.X = s.X; g.ldX = ldX; g.M = s.M; g.Wp = (const __bf16*)s.Wp;
+  g.bias = s.bias; g.gamma = s.gamma; g.beta = s.beta; g.scale = s.scale;
+  g.addend = s.addend; g.ldAdd = ldA; g.dotw = s.dotw; g.dotb = s.dotb;
+  g.Y = s.Y; g.ldY = ldY; g.eps = s.eps; g.relu = s.relu;
+  g.tiles = (int)((s.M + LIN_ROWS - 1) / LIN_ROWS);
+  return 0;
+}
+
+int ocn_linear_grouped(const OcnLinearGroup* groups, int32_t n_groups, int32_t K, int32_t N, void* stream) {
+  if (!groups || n_groups < 1 || n_groups > LIN_MAX_GROUPS || K <= 0 || (K % LIN_KS)) return OCN_EINVAL;
+  LinArgs a;
+  a.n_groups = n_groups;
+  a.K = K;
+  for (int g = 0; g < n_groups; ++g) {
+    const int rc = fill_group(a.g[g], groups[g], K, N);
+    if (rc) return rc;
+  }
+  return launch_linear(a, N, (hipStream_t)stream);
+}
 
 int ocn_linear_bf16x6(const float* X, int64_t M, int32_t K, const void* Wp, int32_t N,
                       const float* bias, const float* gamma, const float* beta, float eps,
                       int32_t relu, const float* dotw, const float* dotb, float* Y, void* stream) {
-  if (M < 0 || K <= 0 || (K % LIN_KS) || N <= 0) return OCN_EINVAL;
-  if (M == 0) return 0;
-  if (!X || !Wp || !Y || ((gamma == nullptr) != (beta == nullptr))) return OCN_EINVAL;
-  switch (N) {
-    case 32:  LAUNCH_LINEAR(1); break;
-    case 64:  LAUNCH_LINEAR(2); break;
-    case 128: LAUNCH_LINEAR(4); break;
-    case 256: LAUNCH_LINEAR(8); break;
-    default: return OCN_EINVAL;
-  }
-  return launch_status();
+  OcnLinearGroup g = {};
+  g.X = X; g.M = M; g.Wp = Wp; g.bias = bias; g.gamma = gamma; g.beta = beta; g.eps = eps; g.relu = relu;
+  g.dotw = dotw; g.dotb = dotb; g.Y = Y;
+  return ocn_linear_grouped(&g, 1, K, N, stream);
 }
 
 }  // extern "C"

@@ -320,6 +320,35 @@ class GCN3(_Encoder):
 # ------------------------------------------------------------------------------------------
 # predictors
 # ------------------------------------------------------------------------------------------
+def _stages(seq: nn.Sequential, H: int):
+    """Parse an eval-mode head into fused stages [(Linear, LayerNorm | None, relu)], or None when a
+    module does not fit the ``Linear [-> LayerNorm] [-> ReLU]`` pattern at width H."""
+    mods = [m for m in seq if not isinstance(m, (nn.Dropout, nn.Identity))]
+    out, i = [], 0
+    while i < len(mods):
+        m = mods[i]
+        if not (isinstance(m, nn.Linear) and m.in_features == H and m.out_features == H and m.bias is not None):
+            return None
+        ln, relu, j = None, False, i + 1
+        if j < len(mods) and isinstance(mods[j], nn.LayerNorm):
+            if not (mods[j].elementwise_affine and tuple(mods[j].normalized_shape) == (H,)):
+                return None
+            ln, j = mods[j], j + 1
+        if j < len(mods) and isinstance(mods[j], nn.ReLU):
+            relu, j = True, j + 1
+        out.append((m, ln, relu))
+        i = j
+    return out
+
+
+def _grp(x, st, y, **extra):
+    lin, ln, relu = st
+    g = dict(x=x, weight=lin.weight, bias=lin.bias, relu=relu, y=y,
+             ln=None if ln is None else (ln.weight, ln.bias, ln.eps))
+    g.update(extra)
+    return g
+
+
 def _seq_eval(seq: nn.Sequential, x: Tensor) -> Tensor:
     """Eval-mode walk of one of the predictor's ``nn.Sequential`` heads.  Dropout/Identity vanish;
     ``Linear [-> LayerNorm] [-> ReLU] [-> Linear(H, 1)]`` runs as one bf16x6 MFMA kernel with the
@@ -398,6 +427,7 @@ class _CNPredictorBase(nn.Module):
         self.register_buffer("innerprod", torch.tensor([0.0]))
         self.n = 0
         self._shard_group, self._sharded = None, False
+        self._ws = {}                          # scratch reused from batch to batch on the no-grad path
 
     def set_edge_sharding(self, group=None, enabled: bool = True) -> None:
         """The candidate batch handed to ``forward`` is one rank's slice of a global batch: sum the
@@ -410,6 +440,11 @@ class _CNPredictorBase(nn.Module):
             allreduce_hist(st.hist, self._shard_group)
             ops._mark("allreduce_hist")
         return st
+
+    def _scratch(self, x):
+        """Reuse scratch across batches only where nothing outlives the call: no autograd graph (it
+        would hold the flag / weight buffers for the backward)."""
+        return None if (torch.is_grad_enabled() and (x.requires_grad or self.training)) else self._ws
 
     def _pool(self, st, w, x):
         x = x.contiguous()
@@ -434,6 +469,7 @@ class _CNPredictorBase(nn.Module):
         eval-path constants, so edits that bypass the version counters (``param.data``) cannot go stale
         across a training pass."""
         self._coef_key = None
+        self._mixw_key = None
         for p in self.parameters():
             ops._panels.pop(id(p), None)
         return super().train(mode)
@@ -448,6 +484,54 @@ class _CNPredictorBase(nn.Module):
             self._coef_key = key
         return self._coef
 
+    def _mix_weight(self, la: nn.Linear, lb: nn.Linear):
+        """[σ(α0)·W3a | σ(α0)σ(α1)·W3b] and the matching bias: the branch mix of model.py:2436 folded
+        into one K = 2H Linear over the concatenated second-layer outputs.  Cached like the panels."""
+        key = (self._mix_coef().data_ptr(), self._coef_key, la.weight.data_ptr(), la.weight._version,
+               lb.weight.data_ptr(), lb.weight._version, la.bias._version, lb.bias._version)
+        if getattr(self, "_mixw_key", None) != key:
+            c = self._mix_coef()
+            with torch.no_grad():
+                self._mixw = torch.cat([c[0] * la.weight, c[1] * lb.weight], dim=1).contiguous()
+                self._mixb = (c[0] * la.bias + c[1] * lb.bias).contiguous()
+            self._mixw_key = key
+        return self._mixw, self._mixb
+
+    def _heads_grouped(self, xcn1, xcn2, xij):
+        """The three branches layer by layer instead of branch by branch: launch 1 = first layers of
+        xcn1lin / xcn2lin / xijlin, launch 2 = their second layers (the two pooled branches write the
+        halves of one [B, 2H] buffer), launch 3 = one K = 2H Linear that is both third layers and the
+        branch mix, with the xij branch as its addend.  Returns None when the heads do not have that
+        shape (then the per-branch walk runs)."""
+        B, H = xij.shape
+        if H not in ops.LINEAR_WIDTHS or not ops.fast_linear or B == 0:
+            return None
+        rows = B * H * 4
+        if not (xcn1.is_contiguous() and xcn2.data_ptr() == xcn1.data_ptr() + rows
+                and xij.data_ptr() == xcn2.data_ptr() + rows):
+            return None
+        sa, sb, sx = _stages(self.xcn1lin, H), _stages(self.xcn2lin, H), _stages(self.xijlin, H)
+        if sa is None or sb is None or sx is None or len(sa) != 3 or len(sb) != 3 or len(sx) not in (1, 2):
+            return None
+        if sa[2][1] is not None or sa[2][2] or sb[2][1] is not None or sb[2][2]:
+            return None
+        coef = self._mix_coef()
+        dev = xij.device
+        y0 = ops.buf(self._ws, "y0", (B, H), torch.float32, dev)           # β · xijlin(x_i ⊙ x_j)
+        t1 = ops.buf(self._ws, "t1", (3 if len(sx) == 2 else 2, B, H), torch.float32, dev)
+        g1 = [_grp(xcn1, sa[0], t1[0]), _grp(xcn2, sb[0], t1[1]),
+              _grp(xij, sx[0], t1[2]) if len(sx) == 2 else _grp(xij, sx[0], y0, scale=coef[2:3])]
+        ops.linear_grouped(g1, H, H)
+        cat = ops.buf(self._ws, "cat", (B, 2 * H), torch.float32, dev)
+        g2 = [_grp(t1[0], sa[1], cat[:, :H]), _grp(t1[1], sb[1], cat[:, H:])]
+        if len(sx) == 2:
+            g2.append(_grp(t1[2], sx[1], y0, scale=coef[2:3]))
+        ops.linear_grouped(g2, H, H)
+        w3, b3 = self._mix_weight(sa[2][0], sb[2][0])
+        z = ops.buf(self._ws, "z", (B, H), torch.float32, dev)
+        ops.linear_grouped([dict(x=cat, weight=w3, bias=b3, relu=False, y=z, addend=y0)], 2 * H, H)
+        return z
+
     def _heads(self, x, xcn1, xcn2, xij):
         if self.training or torch.is_grad_enabled() or not xij.is_cuda or xij.shape[-1] % 4:
             alpha = torch.sigmoid(self.alpha).cumprod(-1)
@@ -455,9 +539,12 @@ class _CNPredictorBase(nn.Module):
             xcn1 = self.xcn1lin(xcn1)
             xcn2 = self.xcn2lin(xcn2)
             return self.lin(alpha[0] * xcn1 + alpha[1] * xcn2 + self.beta * xij)
-        # eval under no_grad (the drivers' test()): same modules, same parameters, walked by
-        # _seq_eval onto the bf16x6 MFMA Linear kernel with fused LayerNorm/ReLU epilogues.  With
-        # autograd on, the torch modules above run instead so that the graph is recorded.
+        # eval under no_grad (the drivers' test()): same modules, same parameters, on the bf16x6 MFMA
+        # Linear kernel with fused LayerNorm/ReLU epilogues.  With autograd on, the torch modules
+        # above run instead so that the graph is recorded.
+        z = self._heads_grouped(xcn1, xcn2, xij)
+        if z is not None:
+            return _seq_eval(self.lin, z)
         xij = _seq_eval(self.xijlin, xij)
         xcn1 = _seq_eval(self.xcn1lin, xcn1)
         xcn2 = _seq_eval(self.xcn2lin, xcn2)
@@ -471,7 +558,7 @@ class CNLinkPredictorOringin(_CNPredictorBase):
 
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
-        st = self._exchange(fuse(cn1, cn2, tar_ei))
+        st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x)))
         w = st.weights_cn5(self.innerprod1(st))
         xcn1, xcn2, xij = self._pool(st, w, x)
         return self._heads(x, xcn1, xcn2, xij)
@@ -486,7 +573,7 @@ class CNLinkPredictorbaselearn(_CNPredictorBase):
 
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, args, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
-        st = self._exchange(fuse(cn1, cn2, tar_ei))
+        st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x)))
         w = st.weights_cn7(float(args.sum))
         xcn1, xcn2, xij = self._pool(st, w, x)
         return self._heads(x, xcn1, xcn2, xij)

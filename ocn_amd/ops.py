@@ -5,6 +5,7 @@ CUDA(HIP) tensors and raises if the library is missing — there is no CPU path.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Optional, Tuple
 
 import torch
@@ -21,9 +22,9 @@ a2_bitmap_max_bytes = 16 << 30   # keep A·B also as dense bit rows when n_rows 
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 
 
-def _mark(name: str) -> None:
+def _mark(name: str, flops: float = 0.0) -> None:
     if stage_timer is not None:
-        stage_timer.mark(name)
+        stage_timer.mark(name, flops)
 
 
 def _req(t: Tensor, dtype, name: str, ndim: Optional[int] = None) -> Tensor:
@@ -42,12 +43,29 @@ def _ws(n: int, device) -> Tensor:
     return torch.empty(int(_lib.lib().ocn_scan_workspace_bytes(n)) // 8 + 1, dtype=torch.int64, device=device)
 
 
-def edge_offsets(rowptr: Tensor, src: Tensor) -> Tensor:
+def buf(ws, name: str, shape, dtype, device, zero: bool = False) -> Tensor:
+    """Scratch tensor.  ``ws`` = None: a fresh allocation (states the caller keeps: tests, materialize).
+    ``ws`` = a dict owned by a predictor: the buffer is cached by (name, shape, dtype) and reused by the
+    next batch — stream order makes that safe, and a dozen allocator round trips per batch disappear
+    from the host's critical path."""
+    shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+    if ws is None:
+        return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+    key = (name, shape, dtype, str(device))
+    t = ws.get(key)
+    if t is None:
+        t = ws[key] = torch.empty(shape, dtype=dtype, device=device)
+    if zero:
+        t.zero_()
+    return t
+
+
+def edge_offsets(rowptr: Tensor, src: Tensor, wsd=None) -> Tensor:
     _req(rowptr, torch.int64, "rowptr", 1)
     _req(src, torch.int64, "src", 1)
     B = src.numel()
-    off = torch.empty(B + 1, dtype=torch.int64, device=src.device)
-    ws = _ws(B, src.device)
+    off = buf(wsd, "off", B + 1, torch.int64, src.device)
+    ws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, src.device)
     check(_lib.lib().ocn_edge_offsets(ptr(rowptr), ptr(src), B, ptr(off), ptr(ws), stream_ptr()),
           "ocn_edge_offsets")
     return off
@@ -86,7 +104,7 @@ def hist_counts(hist: Tensor) -> Tensor:
 
 def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
              t2: Optional[Tuple[Tensor, Tensor]], src: Tensor, dst: Tensor, n_cols: int, max_deg_a: int,
-             walk: bool = False, t2_bitmap: Optional[Tensor] = None):
+             walk: bool = False, t2_bitmap: Optional[Tensor] = None, wsd=None):
     """Intersection pass.  ``walk=False``: flags of N(src) against the rows of dst in t1 (and t2).
     ``walk=True``: the pygho route on A itself (t1/t2 ignored): cn1 flags + walk counts.
     Returns (order|None, off, flags, wc|None, hist[N,2] int64 packed, cnt1, cnt2|None, status)."""
@@ -107,25 +125,26 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     # gather, so visiting them together turns HBM row fetches into L2 hits (outputs stay in batch order)
     order = None
     if B >= sort_edges_min_batch:
-        order = torch.empty(B, dtype=torch.int64, device=dev)
+        order = buf(wsd, "order", B, torch.int64, dev)
         n_src = rowptrA.numel() - 1
-        ows = torch.empty(int(_lib.lib().ocn_order_workspace_bytes(n_src)) // 8 + 1, dtype=torch.int64, device=dev)
+        ows = buf(wsd, "order_ws", int(_lib.lib().ocn_order_workspace_bytes(n_src)) // 8 + 1, torch.int64, dev)
         check(_lib.lib().ocn_order_by_node(ptr(src), B, n_src, ptr(order), ptr(ows), stream_ptr()),
               "ocn_order_by_node")
-    off = edge_offsets(rowptrA, src)
+    off = edge_offsets(rowptrA, src, wsd)
     bound = B * max(int(max_deg_a), 0)
     cap = bound if bound <= FLAGS_NOSYNC_LIMIT else int(off[-1].item())
-    flags = torch.empty(max(cap, 1), dtype=torch.uint8, device=dev)
-    wc = torch.empty(max(cap, 1), dtype=torch.int32, device=dev) if walk else None
-    hist = torch.zeros(n_cols, 2, dtype=torch.int64, device=dev)
-    cnt1 = (torch.zeros if walk else torch.empty)(B, dtype=torch.int32, device=dev)
-    cnt2 = (torch.zeros if walk else torch.empty)(B, dtype=torch.int32, device=dev) if (walk or t2 is not None) else None
+    flags = buf(wsd, "flags", max(cap, 1), torch.uint8, dev)
+    wc = buf(wsd, "wc", max(cap, 1), torch.int32, dev) if walk else None
+    hist = buf(wsd, "hist", (n_cols, 2), torch.int64, dev, zero=True)
+    cnt1 = buf(wsd, "cnt1", B, torch.int32, dev, zero=walk)
+    cnt2 = buf(wsd, "cnt2", B, torch.int32, dev, zero=walk) if (walk or t2 is not None) else None
     chunk_off = None
     if walk:
-        chunk_off = torch.empty(B + 1, dtype=torch.int64, device=dev)
+        chunk_off = buf(wsd, "chunk_off", B + 1, torch.int64, dev)
+        cws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, dev)
         check(_lib.lib().ocn_chunk_offsets(ptr(rowptrA), ptr(src), ptr(order), B, _lib.lib().ocn_walk_chunk(),
-                                           ptr(chunk_off), ptr(_ws(B, dev)), stream_ptr()), "ocn_chunk_offsets")
-    status = torch.zeros(1, dtype=torch.int32, device=dev)
+                                           ptr(chunk_off), ptr(cws), stream_ptr()), "ocn_chunk_offsets")
+    status = buf(wsd, "status", 1, torch.int32, dev, zero=True)
     _mark("cn_prep")
     if walk:
         check(_lib.lib().ocn_cn_walk_flags(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(chunk_off),
@@ -146,11 +165,11 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     return order, off, flags, wc, hist, cnt1, cnt2, status
 
 
-def cn_weights_cn5(hist: Tensor, innerprod: Tensor, valued: bool = False) -> Tensor:
+def cn_weights_cn5(hist: Tensor, innerprod: Tensor, valued: bool = False, wsd=None) -> Tensor:
     """In place: packed int64 [N,2] histogram -> float32 [N,4] weights {w1, t, inv2, 0} (same storage)."""
     _req(hist, torch.int64, "hist", 2)
     ip = _req(innerprod.detach().reshape(1).to(torch.float32), torch.float32, "innerprod", 1)
-    scal = torch.zeros(4, dtype=torch.int32, device=hist.device)
+    scal = buf(wsd, "scal", 4, torch.int32, hist.device, zero=True)
     check(_lib.lib().ocn_cn_weights_cn5(ptr(hist), hist.shape[0], ptr(ip), ptr(scal), int(valued), stream_ptr()),
           "ocn_cn_weights_cn5")
     _mark("cn_weights")
@@ -166,13 +185,13 @@ def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
 
 
 def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights: Tensor, h: Tensor,
-              order: Optional[Tensor] = None, max_row_len: int = 0):
+              order: Optional[Tensor] = None, max_row_len: int = 0, wsd=None):
     _req(weights, torch.float32, "weights", 2)
     _req(h, torch.float32, "h", 2)
     if weights.shape[0] != h.shape[0] or weights.shape[1] != 4:
         raise ValueError("weights must be [N,4] with N = h.shape[0]")
     B, H = src.numel(), h.shape[1]
-    out = torch.empty(3, B, H, dtype=torch.float32, device=h.device)
+    out = buf(wsd, "pooled", (3, B, H), torch.float32, h.device)
     check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags),
                                    ptr(wc), ptr(weights), ptr(h), H, int(max_row_len), ptr(out[0]), ptr(out[1]),
                                    ptr(out[2]), stream_ptr()), "ocn_cn_gather")
@@ -334,5 +353,51 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln=None, re
         dw = dw.reshape(-1)
     check(_lib.lib().ocn_linear_bf16x6(ptr(x), M, K, ptr(panel), N, ptr(bias), ptr(g), ptr(b), float(eps),
                                        int(relu), ptr(dw), ptr(db), ptr(y), stream_ptr()), "ocn_linear_bf16x6")
-    _mark("linear")
+    _mark("linear", 2.0 * M * K * N)
     return y
+
+
+def linear_grouped(groups, K: int, N: int) -> None:
+    """Up to three Linear layers of the same (K, N) in one launch.  Each group is a dict:
+    x [M, >=K] (row stride may exceed K), weight [N, K], y (preallocated, row stride >= N, or [M, 1] with
+    ``dot``), optional bias, ln=(gamma, beta, eps), relu, scale (device float[1]), addend [M, >=N],
+    dot=(w[1, N], b[1])."""
+    if not 1 <= len(groups) <= 3:
+        raise ValueError("1..3 groups")
+    arr = (_lib.OcnLinearGroup * len(groups))()
+    keep = []
+    for a, g in zip(arr, groups):
+        x, w, y = g["x"], g["weight"], g["y"]
+        _req_strided(x, "x"); _req_strided(y, "y")
+        if x.shape[1] != K or tuple(w.shape) != (N, K) or x.shape[0] != y.shape[0]:
+            raise ValueError("linear_grouped: shape mismatch")
+        panel = linear_panel(w)
+        keep.append(panel)
+        ln = g.get("ln")
+        dot = g.get("dot")
+        add = g.get("addend")
+        a.X, a.ldX, a.M, a.Wp = x.data_ptr(), x.stride(0), x.shape[0], panel.data_ptr()
+        a.bias = 0 if g.get("bias") is None else g["bias"].data_ptr()
+        a.gamma, a.beta, a.eps = (0, 0, 0.0) if ln is None else (ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2]))
+        a.relu = int(bool(g.get("relu")))
+        a.scale = 0 if g.get("scale") is None else g["scale"].data_ptr()
+        if add is not None:
+            _req_strided(add, "addend")
+            a.addend, a.ldAdd = add.data_ptr(), add.stride(0)
+        if dot is not None:
+            a.dotw = dot[0].data_ptr()
+            a.dotb = 0 if dot[1] is None else dot[1].data_ptr()
+            a.ldY = 1
+        else:
+            a.ldY = y.stride(0)
+        a.Y = y.data_ptr()
+    _mark("mlp_glue")
+    check(_lib.lib().ocn_linear_grouped(ctypes.cast(arr, ctypes.c_void_p), len(groups), K, N, stream_ptr()),
+          "ocn_linear_grouped")
+    _mark("linear", sum(2.0 * g["x"].shape[0] * K * N for g in groups))
+
+
+def _req_strided(t: Tensor, name: str) -> None:
+    """2-d fp32 device tensor whose rows are contiguous (row stride may exceed the width)."""
+    if not (isinstance(t, Tensor) and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+        raise ValueError(f"{name}: expected a 2-d fp32 device tensor with contiguous rows")

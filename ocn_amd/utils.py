@@ -49,7 +49,7 @@ class CNState:
     {n1, n2, n_union, walks}, and the integer CN counts."""
 
     def __init__(self, adj: SparseTensor, t1: Optional[SparseTensor], t2: Optional[SparseTensor],
-                 tarei: Tensor, walk: bool = False):
+                 tarei: Tensor, walk: bool = False, ws: Optional[dict] = None):
         if tarei.dim() != 2 or tarei.shape[0] != 2:
             raise ValueError("tarei must be [2, B]")
         for t in (t1, t2):
@@ -58,6 +58,7 @@ class CNState:
         if walk and adj.size(0) != adj.size(1):
             raise ValueError("get_cn1_cn2 needs a square adjacency")
         self.adj, self.walk = adj, walk
+        self.ws = ws                           # a predictor's scratch cache: this state is then transient
         self.src = tarei[0].to(torch.int64).contiguous()
         self.dst = tarei[1].to(torch.int64).contiguous()
         self.B = self.src.numel()
@@ -66,7 +67,7 @@ class CNState:
         (self.order, self.off, self.flags, self.wc, self.hist, self.cnt1, self.cnt2, self.status) = ops.cn_flags(
             adj._rowptr, adj._col, None if walk else (t1._rowptr, t1._col),
             None if (walk or t2 is None) else (t2._rowptr, t2._col), self.src, self.dst, self.N,
-            adj.max_rowcount(), walk=walk, t2_bitmap=None if (walk or t2 is None) else t2._bitmap)
+            adj.max_rowcount(), walk=walk, t2_bitmap=None if (walk or t2 is None) else t2._bitmap, wsd=ws)
         self._hist_live = True
 
     def check_status(self) -> None:
@@ -81,7 +82,7 @@ class CNState:
     def weights_cn5(self, innerprod: Tensor) -> Tensor:
         assert self._hist_live, "histogram already consumed"
         self._hist_live = False
-        return ops.cn_weights_cn5(self.hist, innerprod, valued=self.walk)
+        return ops.cn_weights_cn5(self.hist, innerprod, valued=self.walk, wsd=self.ws)
 
     def weights_cn7(self, sum_fill: float) -> Tensor:
         assert self._hist_live, "histogram already consumed"
@@ -91,7 +92,7 @@ class CNState:
     def gather(self, weights: Tensor, h: Tensor):
         return ops.cn_gather(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off,
                              self.flags, self.wc, weights, h, order=self.order,
-                             max_row_len=self.adj.max_rowcount())
+                             max_row_len=self.adj.max_rowcount(), wsd=self.ws)
 
     def gather_backward(self, weights: Tensor, h: Tensor, g1: Tensor, g2: Tensor, g3: Tensor) -> Tensor:
         return ops.cn_gather_backward(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off, self.flags,
@@ -169,7 +170,7 @@ class CNBatch:
         return self._single().materialize(2 if self.mode == "walk2" else 1)
 
 
-def fuse(cn1: CNBatch, cn2: CNBatch, tar_ei: Tensor) -> CNState:
+def fuse(cn1: CNBatch, cn2: CNBatch, tar_ei: Tensor, ws: Optional[dict] = None) -> CNState:
     """One intersection pass for the (cn1, cn2) pair every driver builds from the same candidate
     edges (NeighborOverlap_large.py:76-82,121-159; NeighborOverlap_large_ppa.py:98-133)."""
     if not isinstance(cn1, CNBatch) or not isinstance(cn2, CNBatch):
@@ -182,10 +183,10 @@ def fuse(cn1: CNBatch, cn2: CNBatch, tar_ei: Tensor) -> CNState:
     if ops.validate_indices and not (torch.equal(cn1.tarei, cn2.tarei) and torch.equal(cn1.tarei, tar_ei)):
         raise NotImplementedError("cn1, cn2 and tar_ei must be built from the same candidate edges")
     if cn1.mode == "walk1" and cn2.mode == "walk2":
-        return CNState(cn1.adj1, None, None, cn1.tarei, walk=True)
+        return CNState(cn1.adj1, None, None, cn1.tarei, walk=True, ws=ws)
     if cn1.mode != "pattern" or cn2.mode != "pattern":
         raise NotImplementedError("mixing adjoverlap and get_cn1_cn2 handles in one predictor call")
-    return CNState(cn1.adj1, cn1.adj2, cn2.adj2, cn1.tarei)
+    return CNState(cn1.adj1, cn1.adj2, cn2.adj2, cn1.tarei, ws=ws)
 
 
 def adjoverlap(adj1: SparseTensor, adj2: SparseTensor, tarei: Tensor, filled1: bool = False,
