@@ -55,6 +55,8 @@ class StageTimer:
         # hipEventCreate is the expensive part on a busy host: create the events before the timed
         # region, only record() inside it
         self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(pool)]
+        for ev in self.pool:                   # torch creates the hipEvent lazily, at the first record()
+            ev.record()
 
     def mark(self, name, flops=0.0):
         if not self.active:
@@ -225,6 +227,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
+    ap.add_argument("--prewarm", type=int, default=64, help="untimed runtime pre-warm steps before --warmup")
+    ap.add_argument("--run-ahead", type=int, default=6, help="steps the host may enqueue ahead of the GPU")
     ap.add_argument("--timer-every", type=int, default=8, help="record stage events on every n-th timed step")
     args = ap.parse_args()
 
@@ -262,6 +266,13 @@ def main():
     out = step()                                   # validated once (bounds check + flag capacity)
     torch.cuda.synchronize()
     ops.validate_indices = False                   # same ids every step: no per-step host sync
+    # Runtime pre-warm (untimed, before the W warm-up steps): the HIP runtime grows its internal
+    # command/signal pools in ~35 ms host stalls during the first ~1000 launches of a process; a short
+    # --warmup would otherwise put one of them inside the timed region.
+    for i in range(args.prewarm):
+        step()
+        if i % 4 == 3:
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     timer = None if args.no_stage_timers else StageTimer(pool=32 * (args.steps // args.timer_every + 1))
@@ -270,15 +281,31 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    # Flow control: the host enqueues a step several times faster than the GPU runs it.  Left alone, the
+    # HIP runtime lets ~1000 commands pile up and then blocks the host until the queue has drained
+    # completely (measured: 35 ms stalls, GPU idle at the end of each) — so the host waits on the event of
+    # the step `run_ahead` steps back, as a real scoring loop that consumes its scores would.
+    run_ahead = max(args.run_ahead, 1)
+    ring = [torch.cuda.Event() for _ in range(run_ahead)]
+    for ev in ring:
+        ev.record()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
+    t_wait = 0.0
     for it in range(args.steps):
+        tw = time.perf_counter()
+        ring[it % run_ahead].synchronize()
+        t_wait += time.perf_counter() - tw
         if timer:                                  # stage events on every `timer_every`-th step only: on a busy
             timer.active = it % args.timer_every == 0   # host each hipEventRecord costs tens of microseconds
             timer.mark("begin")
         out = step()
         if timer:
             timer.mark("mlp_glue")
-    t_launch = time.perf_counter() - t0             # host time to enqueue the K steps (GPU still running)
+        ring[it % run_ahead].record()
+        if os.environ.get("OCN_BENCH_DEBUG"):
+            print("step", it, round((time.perf_counter() - t0) * 1e3, 3), file=sys.stderr)
+    t_launch = time.perf_counter() - t0 - t_wait    # host time spent enqueueing the K steps (flow-control waits excluded)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

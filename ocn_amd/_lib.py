@@ -123,5 +123,11 @@ def ptr(t) -> c_void_p:
 
 
 def stream_ptr() -> c_void_p:
+    """torch's current HIP stream of the current device, as a raw hipStream_t.  Through the raw
+    getter: ``torch.cuda.current_stream()`` walks is_available()/os.getenv on every call, which is
+    most of a launch's host cost at nine launches per candidate batch."""
     import torch
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+    if raw is None:
+        return c_void_p(torch.cuda.current_stream().cuda_stream)
+    return c_void_p(raw(torch._C._cuda_getDevice()))
