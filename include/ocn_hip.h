@@ -87,13 +87,28 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA,
  * additionally accumulates walks = sum of the counts of column k; cnt2[e] = number of non-zero
  * entries of cn2 row e.  Work is cut into items of ocn_walk_chunk() neighbours of i (chunk_off from
  * ocn_chunk_offsets), so hub source nodes spread over many workgroups; cnt1 / cnt2 must be ZERO on
- * entry (a row's items add into them). */
+ * entry (a row's items add into them).  `status` is int32[4] here, ZERO on entry: [0] receives the
+ * overflow flag as for ocn_cn_flags, [1] and [2] are the work-item ticket counters of the two sweeps. */
 int32_t ocn_walk_chunk(void);
-int ocn_cn_walk_flags(const int64_t* rowptrA, const int32_t* colA,
+int ocn_cn_walk_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* nds /* or NULL */,
                       const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
-                      const int64_t* chunk_off, const int64_t* off, uint8_t* flags, int32_t* wc, int64_t flags_cap,
+                      const int64_t* chunk_off, const int64_t* rev_off /* NULL iff nds is */, const int64_t* off,
+                      int64_t max_row_len /* longest row of A: sizes the LDS set; <= 0 = unknown */,
+                      uint8_t* flags, int32_t* wc, int64_t flags_cap,
                       uint64_t* hist /* [N][2] */, int32_t* cnt1, int32_t* cnt2,
                       int32_t* status, void* stream);
+
+/* Two-sided enumeration of the same walk counts: cn2[e,k] is the number of 2-walks j -> m -> k, which
+ * can be swept from i's side (Σ_{k∈N(i)} deg k elements) or from j's side (Σ_{m∈N(j)} deg m).  With
+ * nds[v] = Σ_{u∈N(v)} deg u (ocn_neighbor_degree_sum, once per adjacency) and rev_off = exclusive scan
+ * of the reverse work items per batch row (ocn_walk_rev_offsets; 0 for rows swept forward),
+ * ocn_cn_walk_flags sweeps each batch row from its cheaper endpoint; results are identical (integer
+ * counts).  The pygho reference always expands from j (spspmm(Ej, 1, adj, 0)). */
+int ocn_neighbor_degree_sum(const int64_t* rowptr, const int32_t* col, int64_t n_rows, int64_t* out,
+                            void* stream);
+int ocn_walk_rev_offsets(const int64_t* rowptrA, const int64_t* nds, const int64_t* src, const int64_t* dst,
+                         const int64_t* order, int64_t B, int64_t* out /* [B+1] */, void* workspace,
+                         void* stream);
 
 /* Per-column weights, written IN PLACE over hist (uint64[N][2] -> float[N][4]) as
  *   {w1, t, inv2, 0}: a cn1 entry pools with w1; a union entry whose cn2 value is c (1.0 for the

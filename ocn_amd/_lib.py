@@ -30,7 +30,10 @@ SIGNATURES = {
                                _P, _P, _P, _P]),
     "ocn_chunk_offsets": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P, _P]),
     "ocn_walk_chunk": (c_int32, []),
-    "ocn_cn_walk_flags": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P]),
+    "ocn_cn_walk_flags": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P,
+                                    _P, _P]),
+    "ocn_neighbor_degree_sum": (c_int32, [_P, _P, c_int64, _P, _P]),
+    "ocn_walk_rev_offsets": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
     "ocn_cn_weights_cn5": (c_int32, [_P, c_int64, _P, _P, c_int32, _P]),
     "ocn_cn_weights_cn7": (c_int32, [_P, c_int64, c_float, _P]),
     "ocn_cn_gather": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P]),

@@ -167,57 +167,207 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
 // K1 (walk counts): the pygho route of NeighborOverlap_large_ppa.py:147-173 without A².
 // cn1 = N(i) ∩ N(j); cn2[e,k] = |N(k) ∩ N(j)| for k in N(i) (number of 2-walks j -> k), kept if > 0.
 // ---------------------------------------------------------------------------------------------
-#define WALK_CAP 2048       /* |N(j)| up to which N(j) becomes an LDS hash set (load factor <= 1/2) */
-#define WALK_HT 4096
-#define WALK_CHUNK 64       /* neighbours of i per work item */
+// The probed neighbour set is a 256 Kbit Bloom-style bitmap in LDS (one multiplicative hash): building
+// it is one atomicOr per member, probing one LDS read, and it does not care how long the row is (an
+// 8 300-neighbour hub gives 3 % false positives, a typical row 0.1 %).  Elements that pass it — the
+// true hits (~1 % of the swept elements) plus the false positives — are queued in LDS and resolved in
+// bulk, one per thread, by binary search in the sorted CSR row; done inline that search would run with
+// a handful of live lanes on nearly every wave iteration.
+#define WALK_BM_BITS 18
+#define WALK_BM_WORDS (1 << (WALK_BM_BITS - 5))
+#define WALK_Q 2048           /* queue entries; flushed when half full, overflow resolves in place */
 
-__device__ __forceinline__ unsigned walk_hash(int32_t v) { return ((unsigned)v * 2654435761u) >> 20; }   // 12 bits
+__device__ __forceinline__ unsigned walk_bit(int32_t v) { return ((unsigned)v * 2654435761u) >> (32 - WALK_BM_BITS); }
+__device__ __forceinline__ void walk_bm_add(unsigned* bm, int32_t v) {
+  const unsigned b = walk_bit(v);
+  atomicOr(&bm[b >> 5], 1u << (b & 31));
+}
+__device__ __forceinline__ bool walk_bm_maybe(const unsigned* bm, int32_t v) {
+  const unsigned b = walk_bit(v);
+  return (bm[b >> 5] >> (b & 31)) & 1u;
+}
 
-__device__ __forceinline__ bool walk_ht_has(const int32_t* ht, int32_t key) {
-  unsigned s = walk_hash(key);
-  for (;;) {
-    const int32_t t = ht[s];
-    if (t == key) return true;
-    if (t < 0) return false;
-    s = (s + 1) & (WALK_HT - 1);
+// position of key in the sorted row a[0..n), or -1
+__device__ __forceinline__ i64 sorted_find(const int32_t* __restrict__ a, i64 n, int32_t key) {
+  i64 lo = 0, hi = n;
+  while (lo < hi) {
+    const i64 mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return (lo < n && a[lo] == key) ? lo : -1;
+}
+
+// batch slot of a work item: last slot with item_off[slot] <= item
+__device__ __forceinline__ i64 walk_item_slot(const i64* __restrict__ item_off, i64 B, i64 item) {
+  i64 lo = 0, hi = B;
+  while (lo < hi) {
+    const i64 mid = (lo + hi) >> 1;
+    if (item_off[mid + 1] <= item) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// The rows of one chunk, flattened: wave 0 loads the chunk's row ids / starts and the exclusive
+// prefix of their lengths; element x of the concatenation belongs to the last row t with
+// s_pre[t] <= x (s_pre[n_rows..2*WALK_CHUNK) = INT_MAX).
+__device__ __forceinline__ void walk_chunk_rows(const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+                                                i64 first, int n_rows, int lane, int* s_pre, i64* s_r0,
+                                                int32_t* s_r, int* s_total) {
+  int32_t r = 0;
+  i64 r0 = 0, dr = 0;
+  if (lane < n_rows) { r = colA[first + lane]; r0 = rowptrA[r]; dr = rowptrA[r + 1] - r0; }
+  const i64 incl = wave_incl_scan(dr, lane);                 // <= 64 x max degree: far below 2^31
+  s_pre[lane] = lane < n_rows ? (int)(incl - dr) : 0x7fffffff;
+  s_pre[lane + WALK_CHUNK] = 0x7fffffff;
+  s_r[lane] = r; s_r0[lane] = r0;
+  if (lane == OCN_WAVE - 1) *s_total = (int)incl;
+}
+
+// One work item of either direction: `rows` = a chunk of <= 64 neighbours of the sweeping endpoint
+// (prepared by walk_chunk_rows), `set_g[0..ds)` = the sorted neighbour row of the other endpoint whose
+// bitmap is in s_bm.  Calls hit(key, row_in_chunk, position_in_set) for every swept element that is
+// a member of the set.
+template <typename Hit>
+__device__ __forceinline__ void walk_sweep(const int32_t* __restrict__ colA, const unsigned* s_bm, const int* s_pre,
+                                           const i64* s_r0, int total, const int32_t* __restrict__ set_g, i64 ds,
+                                           int32_t* s_qk, uint8_t* s_qr, int* s_nq, Hit hit) {
+#ifndef OCN_X_WALK_WU
+#define OCN_X_WALK_WU 8
+#endif
+  constexpr int WU = OCN_X_WALK_WU;          // independent element loads in flight per thread
+  int lo = 0;                                // a thread's elements come in increasing x: the row pointer only moves forward
+  for (int x0 = 0; x0 < total; x0 += WU * OCN_BLOCK) {              // workgroup-uniform trip count
+    int row[WU];
+    int32_t m[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      const int x = x0 + u * OCN_BLOCK + threadIdx.x;
+      m[u] = -1;
+      if (x < total) {
+        while (s_pre[lo + 1] <= x) ++lo;     // <= 64 advances over the whole item; s_pre[n_rows..] = INT_MAX
+        m[u] = colA[s_r0[lo] + (x - s_pre[lo])];
+      }
+      row[u] = lo;
+    }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      if (m[u] >= 0 && walk_bm_maybe(s_bm, m[u])) {
+        const int q = atomicAdd(s_nq, 1);
+        if (q < WALK_Q) { s_qk[q] = m[u]; s_qr[q] = (uint8_t)row[u]; }
+        else {                                                      // queue full (dense overlap): resolve in place
+          const i64 pos = sorted_find(set_g, ds, m[u]);
+          if (pos >= 0) hit(m[u], row[u], pos);
+        }
+      }
+    }
+    __syncthreads();
+    if (*s_nq > WALK_Q / 2 || x0 + WU * OCN_BLOCK >= total) {
+      const int nq = *s_nq < WALK_Q ? *s_nq : WALK_Q;
+      for (int q = threadIdx.x; q < nq; q += OCN_BLOCK) {
+        const i64 pos = sorted_find(set_g, ds, s_qk[q]);
+        if (pos >= 0) hit(s_qk[q], (int)s_qr[q], pos);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) *s_nq = 0;
+      __syncthreads();
+    }
   }
 }
 
-// Work item = (batch row, chunk of WALK_CHUNK neighbours k of i); items are enumerated through the
-// exclusive scan chunk_off[] so that a hub source node is spread over many workgroups instead of
-// serialising one.  Per item: N(j) becomes an open-addressing hash set in LDS (~1.5 probes per
-// lookup instead of log2 |N(j)|), and the members of the chunk's rows N(k) are FLATTENED: the 256
-// threads sweep the concatenation of the rows (element -> row by a 6-step search of the chunk's
-// prefix sums), so short rows do not idle lanes, no load waits on a per-row pointer chase, and a
-// hub k costs what its length costs.  Hits (rare) bump the row's counter with an LDS atomic.
-// |N(j)| > WALK_CAP falls back to binary search in memory.
-__global__ __launch_bounds__(OCN_BLOCK) void cn_walk_kernel(
+// Reverse sweep (runs first, only for the batch rows walk_reverse() selects): work item = (batch row,
+// chunk of WALK_CHUNK neighbours m of j).  The members k' of the rows N(m) are probed against N(i);
+// a hit adds one walk to wc[off[e] + position of k' in N(i)] (wc is zero on entry).  The forward
+// kernel's items of that batch row then only finalise it.
+__global__ __launch_bounds__(OCN_BLOCK) void cn_walk_rev_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
+    const i64* __restrict__ rev_off, const i64* __restrict__ off, int32_t* __restrict__ wc, i64 cap,
+    int32_t* __restrict__ ticket) {
+  __shared__ unsigned s_bm[WALK_BM_WORDS];
+  __shared__ int s_pre[2 * WALK_CHUNK];
+  __shared__ i64 s_m0[WALK_CHUNK];
+  __shared__ int32_t s_m[WALK_CHUNK];
+  __shared__ int32_t s_qk[WALK_Q];
+  __shared__ uint8_t s_qr[WALK_Q];
+  __shared__ int s_nq;
+  __shared__ i64 s_slot, s_item;
+  __shared__ int s_total;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const i64 n_items = rev_off[B];
+  for (;;) {                                   // items differ 100x in cost: workgroups draw them from a ticket counter
+    if (threadIdx.x == 0) {
+      s_item = atomicAdd(ticket, 1);
+      if (s_item < n_items) s_slot = walk_item_slot(rev_off, B, s_item);
+      s_nq = 0;
+    }
+    for (int q = threadIdx.x; q < WALK_BM_WORDS; q += OCN_BLOCK) s_bm[q] = 0u;
+    __syncthreads();
+    const i64 item = s_item;
+    if (item >= n_items) break;
+    const i64 slot = s_slot;
+    const i64 e = order ? order[slot] : slot;
+    const i64 i = src[e], j = dst[e];
+    const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+    const i64 b0 = rowptrA[j], db = rowptrA[j + 1] - b0;
+    const i64 base = off[e];
+    const i64 p_lo = (item - rev_off[slot]) * WALK_CHUNK;
+    const int nm = (int)(((p_lo + WALK_CHUNK) < db ? (p_lo + WALK_CHUNK) : db) - p_lo);
+    const int32_t* ni_g = colA + a0;
+    if (w == 0) {
+      walk_chunk_rows(rowptrA, colA, b0 + p_lo, nm, lane, s_pre, s_m0, s_m, &s_total);
+    } else {
+      for (i64 q = threadIdx.x - OCN_WAVE; q < da; q += OCN_BLOCK - OCN_WAVE) walk_bm_add(s_bm, ni_g[q]);
+    }
+    __syncthreads();
+#ifdef OCN_X_WALK_NOSWEEP   /* timing experiment: per-item overhead only */
+    const int total = 0;
+#else
+    const int total = base + da <= cap ? s_total : 0;
+#endif
+    int32_t* wrow = wc + base;
+    walk_sweep(colA, s_bm, s_pre, s_m0, total, ni_g, da, s_qk, s_qr, &s_nq,
+               [wrow](int32_t, int, i64 pos) { atomicAdd(wrow + pos, 1); });
+    __syncthreads();
+  }
+}
+
+// Forward sweep.  Work item = (batch row, chunk of WALK_CHUNK neighbours k of i); items are enumerated
+// through the exclusive scan chunk_off[] so that a hub source node is spread over many workgroups
+// instead of serialising one.  The members of the chunk's rows N(k) are FLATTENED: the 256 threads
+// sweep the concatenation of the rows, so short rows do not idle lanes, no load waits on a per-row
+// pointer chase, and a hub k costs what its length costs; each is probed against N(j), and a hit
+// bumps the row's counter with an LDS atomic.  For a batch row the reverse sweep has already counted
+// (walk_reverse()), the item only reads its counts back from wc and finalises flags, histogram and
+// per-edge counts.
+__global__ __launch_bounds__(OCN_BLOCK) void cn_walk_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA, const i64* __restrict__ nds,
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     const i64* __restrict__ chunk_off, const i64* __restrict__ off, uint8_t* __restrict__ flags,
     int32_t* __restrict__ wc, i64 cap, u64* __restrict__ hist, int32_t* __restrict__ cnt1,
-    int32_t* __restrict__ cnt2, int32_t* __restrict__ status) {
-  __shared__ int32_t s_ht[WALK_HT];
+    int32_t* __restrict__ cnt2, int32_t* __restrict__ status) {   // status[0] flags, [1] / [2] item tickets (zero on entry)
+  __shared__ unsigned s_bm[WALK_BM_WORDS];
   __shared__ int s_pre[2 * WALK_CHUNK];      // exclusive prefix of the chunk's row lengths; [nk..] = INT_MAX
   __shared__ i64 s_k0[WALK_CHUNK];
   __shared__ int32_t s_k[WALK_CHUNK];
   __shared__ int s_walks[WALK_CHUNK];
-  __shared__ i64 s_slot;
+  __shared__ int32_t s_qk[WALK_Q];
+  __shared__ uint8_t s_qr[WALK_Q];
+  __shared__ int s_nq;
+  __shared__ i64 s_slot, s_item;
   __shared__ int s_total;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (blockIdx.x == 0 && threadIdx.x == 0 && off[B] > cap) atomicOr(status, 1);
   const i64 n_items = chunk_off[B];
-  for (i64 item = blockIdx.x; item < n_items; item += gridDim.x) {
-    if (threadIdx.x == 0) {                    // batch row of this item: last slot with chunk_off[slot] <= item
-      i64 lo = 0, hi = B;
-      while (lo < hi) {
-        const i64 mid = (lo + hi) >> 1;
-        if (chunk_off[mid + 1] <= item) lo = mid + 1; else hi = mid;
-      }
-      s_slot = lo;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      s_item = atomicAdd(status + 1, 1);
+      if (s_item < n_items) s_slot = walk_item_slot(chunk_off, B, s_item);
+      s_nq = 0;
     }
-    for (int q = threadIdx.x; q < WALK_HT; q += OCN_BLOCK) s_ht[q] = -1;
+    for (int q = threadIdx.x; q < WALK_BM_WORDS; q += OCN_BLOCK) s_bm[q] = 0u;
     __syncthreads();
+    const i64 item = s_item;
+    if (item >= n_items) break;
     const i64 slot = s_slot;
     const i64 e = order ? order[slot] : slot;
     const i64 i = src[e], j = dst[e];
@@ -226,58 +376,35 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_walk_kernel(
     const i64 base = off[e];
     const i64 p_lo = (item - chunk_off[slot]) * WALK_CHUNK;
     const int nk = (int)(((p_lo + WALK_CHUNK) < da ? (p_lo + WALK_CHUNK) : da) - p_lo);
-    const bool nj_lds = db <= WALK_CAP;
+    const bool rev = walk_reverse(nds, i, j, da, db);      // workgroup-uniform
     const int32_t* nj_g = colA + b0;
     if (w == 0) {                              // the chunk's rows: ids, starts, prefix sums of lengths
-      int32_t k = 0;
-      i64 k0 = 0, dk = 0;
-      if (lane < nk) { k = colA[a0 + p_lo + lane]; k0 = rowptrA[k]; dk = rowptrA[k + 1] - k0; }
-      const i64 incl = wave_incl_scan(dk, lane);           // <= 64 x max degree: far below 2^31
-      const i64 excl = incl - dk;
-      s_pre[lane] = lane < nk ? (int)excl : 0x7fffffff;
-      s_pre[lane + WALK_CHUNK] = 0x7fffffff;               // padding: the 6-step search below never branches on nk
-      s_k[lane] = k; s_k0[lane] = k0; s_walks[lane] = 0;
-      if (lane == OCN_WAVE - 1) s_total = (int)incl;
-    } else if (nj_lds) {                       // meanwhile the other waves hash N(j)
-      for (i64 q = threadIdx.x - OCN_WAVE; q < db; q += OCN_BLOCK - OCN_WAVE) {
-        const int32_t v = colA[b0 + q];
-        unsigned s = walk_hash(v);
-        while (atomicCAS(&s_ht[s], -1, v) != -1) s = (s + 1) & (WALK_HT - 1);
-      }
+      walk_chunk_rows(rowptrA, colA, a0 + p_lo, nk, lane, s_pre, s_k0, s_k, &s_total);
+      s_walks[lane] = 0;
+    } else {                                   // meanwhile the other waves set N(j)'s bits
+      for (i64 q = threadIdx.x - OCN_WAVE; q < db; q += OCN_BLOCK - OCN_WAVE) walk_bm_add(s_bm, nj_g[q]);
     }
     __syncthreads();
-    const int total = s_total;
-    constexpr int WU = 4;                      // independent element chains in flight per thread
-    for (int x0 = threadIdx.x; x0 < total; x0 += WU * OCN_BLOCK) {
-      int row[WU];
-      int32_t m[WU];
-#pragma unroll
-      for (int u = 0; u < WU; ++u) {
-        const int x = x0 + u * OCN_BLOCK;
-        int lo = 0;                            // row of element x: last t with s_pre[t] <= x (s_pre[0] = 0)
-#pragma unroll
-        for (int st = WALK_CHUNK / 2; st > 0; st >>= 1)
-          if (s_pre[lo + st] <= x) lo += st;
-        row[u] = lo;
-        m[u] = x < total ? colA[s_k0[lo] + (x - s_pre[lo])] : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < WU; ++u) {
-        if (m[u] >= 0 && (nj_lds ? walk_ht_has(s_ht, m[u]) : sorted_has(nj_g, db, m[u])))
-          atomicAdd(&s_walks[row[u]], 1);
-      }
-    }
+#ifdef OCN_X_WALK_NOSWEEP
+    const int total = 0;
+#else
+    const int total = rev ? 0 : s_total;
+#endif
+    int* walks_of = s_walks;
+    walk_sweep(colA, s_bm, s_pre, s_k0, total, nj_g, db, s_qk, s_qr, &s_nq,
+               [walks_of](int32_t, int row, i64) { atomicAdd(walks_of + row, 1); });
     __syncthreads();
     if (w == 0) {
       bool f1 = false, f2 = false;
       if (lane < nk) {
         const int32_t k = s_k[lane];
-        const int walks = s_walks[lane];
-        f1 = nj_lds ? walk_ht_has(s_ht, k) : sorted_has(nj_g, db, k);
+        const bool in_cap = base + da <= cap;
+        const int walks = rev ? (in_cap ? wc[base + p_lo + lane] : 0) : s_walks[lane];
+        f1 = walk_bm_maybe(s_bm, k) && sorted_has(nj_g, db, k);
         f2 = walks > 0;
-        if (base + da <= cap) {
+        if (in_cap) {
           flags[base + p_lo + lane] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
-          wc[base + p_lo + lane] = walks;
+          if (!rev) wc[base + p_lo + lane] = walks;
         }
         if (f1 | f2) {
           atomicAdd(hist + 2 * (i64)k, (u64)f1 | ((u64)f2 << HF_BITS) | (1ull << (2 * HF_BITS)));
@@ -291,6 +418,30 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_walk_kernel(
       }
     }
     __syncthreads();
+  }
+}
+
+// wc[0 .. min(off[B], cap)) = 0: the reverse sweep accumulates into it
+__global__ __launch_bounds__(OCN_BLOCK) void walk_zero_kernel(const i64* __restrict__ off, i64 B, i64 cap,
+                                                              int32_t* __restrict__ wc) {
+  i64 n = off[B];
+  if (n > cap) n = cap;
+  for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (i64)gridDim.x * blockDim.x) wc[q] = 0;
+}
+
+// nds[v] = Σ_{u ∈ N(v)} deg(u): the number of elements a sweep of v's neighbour rows touches
+__global__ __launch_bounds__(OCN_BLOCK) void neighbor_degree_sum_kernel(const i64* __restrict__ rowptr,
+                                                                        const int32_t* __restrict__ col, i64 n,
+                                                                        i64* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  for (i64 v = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; v < n; v += ((i64)gridDim.x * blockDim.x) >> 6) {
+    i64 s = 0;
+    for (i64 p = rowptr[v] + lane; p < rowptr[v + 1]; p += OCN_WAVE) {
+      const int32_t u = col[p];
+      s += rowptr[u + 1] - rowptr[u];
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[v] = s;
   }
 }
 
@@ -399,45 +550,63 @@ __device__ __forceinline__ void pool_range(i64 p_begin, i64 p_end, i64 a0, i64 b
                                            const float4* __restrict__ h4, i64 rowq, float4 (&acc1)[NV],
                                            float4 (&acc2)[NV]) {
   constexpr int UNR = 4;
-  for (i64 p0 = p_begin; p0 < p_end; p0 += LPE) {
-    const i64 p = p0 + gl;
-    int32_t k = 0;
-    unsigned f = 0;
-    if (p < p_end) { k = colA[a0 + p]; f = flags[base + p]; }
-    float wa = 0.f, wb = 0.f;
-    if (f) entry_weights(f, weights[k], wc ? (float)wc[base + p] : 1.0f, wa, wb);
-    const bool need = (wa != 0.f) | (wb != 0.f);
-    unsigned long long m = __ballot(need);
-    if (LPE < 64) m = (m >> gbase) & ((1ull << (LPE & 63)) - 1ull);
-    while (m) {
-      int bsel[UNR];
+  // Narrow groups (small H) would otherwise pay one dependent load chain (column id -> column weights)
+  // per LPE positions: a lane fetches PT positions per round, so a round always covers 64 of them.
+  constexpr int PT = (OCN_WAVE / LPE) < 8 ? (OCN_WAVE / LPE) : 8;
+  for (i64 p0 = p_begin; p0 < p_end; p0 += LPE * PT) {
+    int32_t k[PT];
+    unsigned f[PT];
+    int32_t cv[PT];
 #pragma unroll
-      for (int t = 0; t < UNR; ++t) {
-        bsel[t] = m ? (__ffsll((long long)m) - 1) : -1;
-        m &= m - 1;                          // no-op once m == 0
+    for (int t = 0; t < PT; ++t) {
+      const i64 p = p0 + t * LPE + gl;
+      k[t] = 0; f[t] = 0; cv[t] = 1;
+      if (p < p_end) {
+        k[t] = colA[a0 + p]; f[t] = flags[base + p];
+        if (wc) cv[t] = wc[base + p];
       }
-      int32_t kk[UNR];
-      float wwa[UNR], wwb[UNR];
-      float4 x[UNR][NV];
+    }
+    float wa[PT], wb[PT];
 #pragma unroll
-      for (int t = 0; t < UNR; ++t) {
-        const int sl = gbase + (bsel[t] < 0 ? 0 : bsel[t]);
-        kk[t] = __shfl(k, sl, OCN_WAVE);
-        wwa[t] = __shfl(wa, sl, OCN_WAVE);
-        wwb[t] = __shfl(wb, sl, OCN_WAVE);
-        if (bsel[t] >= 0) {
-          const float4* row = h4 + (i64)kk[t] * rowq + gl;
+    for (int t = 0; t < PT; ++t) {
+      wa[t] = wb[t] = 0.f;
+      if (f[t]) entry_weights(f[t], weights[k[t]], (float)cv[t], wa[t], wb[t]);
+    }
 #pragma unroll
-          for (int v = 0; v < NV; ++v) x[t][v] = row[v * LPE];
+    for (int t = 0; t < PT; ++t) {             // ascending position order: tile t, then lane
+      const bool need = (wa[t] != 0.f) | (wb[t] != 0.f);
+      unsigned long long m = __ballot(need);
+      if (LPE < 64) m = (m >> gbase) & ((1ull << (LPE & 63)) - 1ull);
+      while (m) {
+        int bsel[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          bsel[u] = m ? (__ffsll((long long)m) - 1) : -1;
+          m &= m - 1;                          // no-op once m == 0
         }
-      }
+        int32_t kk[UNR];
+        float wwa[UNR], wwb[UNR];
+        float4 x[UNR][NV];
 #pragma unroll
-      for (int t = 0; t < UNR; ++t) {
-        if (bsel[t] >= 0) {
+        for (int u = 0; u < UNR; ++u) {
+          const int sl = gbase + (bsel[u] < 0 ? 0 : bsel[u]);
+          kk[u] = __shfl(k[t], sl, OCN_WAVE);
+          wwa[u] = __shfl(wa[t], sl, OCN_WAVE);
+          wwb[u] = __shfl(wb[t], sl, OCN_WAVE);
+          if (bsel[u] >= 0) {
+            const float4* row = h4 + (i64)kk[u] * rowq + gl;
 #pragma unroll
-          for (int v = 0; v < NV; ++v) {
-            axpy4(acc1[v], wwa[t], x[t][v]);
-            axpy4(acc2[v], wwb[t], x[t][v]);
+            for (int v = 0; v < NV; ++v) x[u][v] = row[v * LPE];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          if (bsel[u] >= 0) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+              axpy4(acc1[v], wwa[u], x[u][v]);
+              axpy4(acc2[v], wwb[u], x[u][v]);
+            }
           }
         }
       }
@@ -723,19 +892,39 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
   return launch_status();
 }
 
-int ocn_cn_walk_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
+int ocn_cn_walk_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* nds, const int64_t* src,
                       const int64_t* dst, const int64_t* order, int64_t B, const int64_t* chunk_off,
-                      const int64_t* off, uint8_t* flags, int32_t* wc, int64_t flags_cap, uint64_t* hist,
-                      int32_t* cnt1, int32_t* cnt2, int32_t* status, void* stream) {
+                      const int64_t* rev_off, const int64_t* off, int64_t max_row_len, uint8_t* flags, int32_t* wc,
+                      int64_t flags_cap, uint64_t* hist, int32_t* cnt1, int32_t* cnt2, int32_t* status,
+                      void* stream) {
   if (B < 0 || flags_cap < 0 || B > (int64_t)HF_MASK) return OCN_EINVAL;
   if (B == 0) return 0;
   if (!rowptrA || !src || !dst || !chunk_off || !off || !hist || !cnt1 || !cnt2 || !status) return OCN_EINVAL;
   if (flags_cap > 0 && (!flags || !wc)) return OCN_EINVAL;
-  // the item count lives on the device (chunk_off[B]); a fixed grid strides over it
-  const int grid = grid_for(4 * B, 256 * 16);
-  hipLaunchKernelGGL(cn_walk_kernel, dim3(grid), dim3(OCN_BLOCK), 0, (hipStream_t)stream,
-                     (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B,
-                     (const i64*)chunk_off, (const i64*)off, flags, wc, (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
+  if ((nds == nullptr) != (rev_off == nullptr)) return OCN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  (void)max_row_len;
+  // the item counts live on the device (chunk_off[B], rev_off[B]); fixed grids stride over them
+  const int grid = grid_for(4 * B, 256 * 4);   // what can be resident; the items are drawn from a ticket counter
+  if (nds && flags_cap > 0) {
+    hipLaunchKernelGGL(walk_zero_kernel, dim3(grid_for((flags_cap + OCN_BLOCK - 1) / OCN_BLOCK, 2048)),
+                       dim3(OCN_BLOCK), 0, st, (const i64*)off, (i64)B, (i64)flags_cap, wc);
+    hipLaunchKernelGGL(cn_walk_rev_kernel, dim3(grid), dim3(OCN_BLOCK), 0, st,
+                       (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B,
+                       (const i64*)rev_off, (const i64*)off, wc, (i64)flags_cap, status + 2);
+  }
+  hipLaunchKernelGGL(cn_walk_kernel, dim3(grid), dim3(OCN_BLOCK), 0, st,
+                     (const i64*)rowptrA, colA, (const i64*)(flags_cap > 0 ? nds : nullptr), (const i64*)src,
+                     (const i64*)dst, (const i64*)order, (i64)B, (const i64*)chunk_off, (const i64*)off, flags, wc,
+                     (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
+  return launch_status();
+}
+
+int ocn_neighbor_degree_sum(const int64_t* rowptr, const int32_t* col, int64_t n_rows, int64_t* out, void* stream) {
+  if (n_rows < 0 || (n_rows > 0 && (!rowptr || !out))) return OCN_EINVAL;
+  if (n_rows == 0) return 0;
+  hipLaunchKernelGGL(neighbor_degree_sum_kernel, dim3(grid_for((n_rows + OCN_WPB - 1) / OCN_WPB, 1 << 16)),
+                     dim3(OCN_BLOCK), 0, (hipStream_t)stream, (const i64*)rowptr, col, (i64)n_rows, (i64*)out);
   return launch_status();
 }
 

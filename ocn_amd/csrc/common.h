@@ -56,6 +56,22 @@ __device__ __forceinline__ i64 block_excl_scan(i64 v, i64* sh, i64* total) {
   return base + inc - v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// walk-count route: which endpoint enumerates the 2-walks of a candidate edge (i, j)
+// ---------------------------------------------------------------------------------------------
+// cn2[e,k] = |N(k) ∩ N(j)| for k in N(i) is the number of 2-walks j -> m -> k.  "Forward" sweeps the
+// rows N(k), k in N(i) (nds[i] = Σ_{k∈N(i)} d_k probes against N(j)); "reverse" sweeps the rows N(m),
+// m in N(j) (nds[j] probes against N(i); its hits land through global atomics, each 64-chunk of N(j)
+// sets up N(i)'s bitmap again, and the row is finalised by the forward kernel's items afterwards).
+// A hub source with a modest target is 10-100x cheaper from the target's side.
+#define WALK_CHUNK 64        /* rows (neighbours) per work item, either direction */
+__device__ __forceinline__ bool walk_reverse(const i64* __restrict__ nds, i64 i, i64 j, i64 di, i64 dj) {
+  if (!nds || dj == 0 || di == 0) return false;
+  const i64 chunks_j = (dj + WALK_CHUNK - 1) / WALK_CHUNK;
+  const i64 rev = 2 * nds[j] + 2 * di * chunks_j + 2 * di;
+  return rev < nds[i];
+}
+
 __device__ __forceinline__ void axpy4(float4& acc, float w, const float4& x) {
   acc.x = __fadd_rn(acc.x, __fmul_rn(w, x.x));
   acc.y = __fadd_rn(acc.y, __fmul_rn(w, x.y));

@@ -181,9 +181,11 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(const LinAr
           __builtin_amdgcn_sched_barrier(0);               // keep the next tile's LDS reads ahead of these MFMAs
           const bf16x8 b1 = bq[t & 1][0], b2 = bq[t & 1][1], b3 = bq[t & 1][2];
           // smallest cross terms first
+#ifndef OCN_X_LIN_T3    /* timing experiment: three cross terms only (what a 2-way split would issue) */
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[t], 0, 0, 0);
+#endif
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[t], 0, 0, 0);

@@ -25,6 +25,19 @@ struct ChunksOfSlot {      // ceil(deg(src[order[slot]]) / chunk): work items of
     return (rowptr[i + 1] - rowptr[i] + chunk - 1) / chunk;
   }
 };
+struct RevChunksOfSlot {   // reverse-sweep work items of a batch row: ceil(deg(dst) / chunk) where walk_reverse(), else 0
+  const i64* rowptr;
+  const i64* nds;
+  const i64* src;
+  const i64* dst;
+  const i64* order;
+  __device__ __forceinline__ i64 operator()(i64 slot) const {
+    const i64 e = order ? order[slot] : slot;
+    const i64 i = src[e], j = dst[e];
+    const i64 di = rowptr[i + 1] - rowptr[i], dj = rowptr[j + 1] - rowptr[j];
+    return walk_reverse(nds, i, j, di, dj) ? (dj + WALK_CHUNK - 1) / WALK_CHUNK : 0;
+  }
+};
 struct I32In {
   const int32_t* in;
   __device__ __forceinline__ i64 operator()(i64 e) const { return (i64)in[e]; }
@@ -170,6 +183,13 @@ int ocn_chunk_offsets(const int64_t* rowptrA, const int64_t* src, const int64_t*
                       int32_t chunk, int64_t* out, void* workspace, void* stream) {
   if (!rowptrA || (!src && B > 0) || chunk <= 0) return OCN_EINVAL;
   ChunksOfSlot op{(const i64*)rowptrA, (const i64*)src, (const i64*)order, (i64)chunk};
+  return run_scan(op, B, (i64*)out, workspace, (hipStream_t)stream);
+}
+
+int ocn_walk_rev_offsets(const int64_t* rowptrA, const int64_t* nds, const int64_t* src, const int64_t* dst,
+                         const int64_t* order, int64_t B, int64_t* out, void* workspace, void* stream) {
+  if (!rowptrA || !nds || ((!src || !dst) && B > 0)) return OCN_EINVAL;
+  RevChunksOfSlot op{(const i64*)rowptrA, (const i64*)nds, (const i64*)src, (const i64*)dst, (const i64*)order};
   return run_scan(op, B, (i64*)out, workspace, (hipStream_t)stream);
 }
 

@@ -19,6 +19,7 @@ validate_indices = True          # bounds-check candidate edges on the host side
 stage_timer = None               # optional object with .mark(name): bench.py records HIP events between stages
 LN_WIDTHS = (16, 32, 64, 128, 256, 512)   # row widths of the lane-group kernels (LayerNorm, pooling backward)
 a2_bitmap_max_bytes = 16 << 30   # keep A·B also as dense bit rows when n_rows * n_cols / 8 fits this budget
+walk_two_sided = True            # walk route: sweep each candidate from its cheaper endpoint (needs nds of the adjacency)
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 
 
@@ -104,9 +105,10 @@ def hist_counts(hist: Tensor) -> Tensor:
 
 def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
              t2: Optional[Tuple[Tensor, Tensor]], src: Tensor, dst: Tensor, n_cols: int, max_deg_a: int,
-             walk: bool = False, t2_bitmap: Optional[Tensor] = None, wsd=None):
+             walk: bool = False, t2_bitmap: Optional[Tensor] = None, wsd=None, nds: Optional[Tensor] = None):
     """Intersection pass.  ``walk=False``: flags of N(src) against the rows of dst in t1 (and t2).
-    ``walk=True``: the pygho route on A itself (t1/t2 ignored): cn1 flags + walk counts.
+    ``walk=True``: the pygho route on A itself (t1/t2 ignored): cn1 flags + walk counts; with ``nds``
+    (``neighbor_degree_sum`` of A) every batch row is swept from its cheaper endpoint.
     Returns (order|None, off, flags, wc|None, hist[N,2] int64 packed, cnt1, cnt2|None, status)."""
     dev = src.device
     B = src.numel()
@@ -138,17 +140,26 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     hist = buf(wsd, "hist", (n_cols, 2), torch.int64, dev, zero=True)
     cnt1 = buf(wsd, "cnt1", B, torch.int32, dev, zero=walk)
     cnt2 = buf(wsd, "cnt2", B, torch.int32, dev, zero=walk) if (walk or t2 is not None) else None
-    chunk_off = None
+    chunk_off = rev_off = None
     if walk:
         chunk_off = buf(wsd, "chunk_off", B + 1, torch.int64, dev)
         cws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, dev)
         check(_lib.lib().ocn_chunk_offsets(ptr(rowptrA), ptr(src), ptr(order), B, _lib.lib().ocn_walk_chunk(),
                                            ptr(chunk_off), ptr(cws), stream_ptr()), "ocn_chunk_offsets")
-    status = buf(wsd, "status", 1, torch.int32, dev, zero=True)
+        if nds is not None and walk_two_sided:
+            _req(nds, torch.int64, "nds", 1)
+            if nds.numel() != rowptrA.numel() - 1:
+                raise ValueError("nds does not match the adjacency")
+            rev_off = buf(wsd, "rev_off", B + 1, torch.int64, dev)
+            check(_lib.lib().ocn_walk_rev_offsets(ptr(rowptrA), ptr(nds), ptr(src), ptr(dst), ptr(order), B,
+                                                  ptr(rev_off), ptr(cws), stream_ptr()), "ocn_walk_rev_offsets")
+        else:
+            nds = None
+    status = buf(wsd, "status", 4, torch.int32, dev, zero=True)     # [0] overflow flag; [1], [2] walk-route work tickets
     _mark("cn_prep")
     if walk:
-        check(_lib.lib().ocn_cn_walk_flags(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(chunk_off),
-                                           ptr(off), ptr(flags),
+        check(_lib.lib().ocn_cn_walk_flags(ptr(rowptrA), ptr(colA), ptr(nds), ptr(src), ptr(dst), ptr(order), B,
+                                           ptr(chunk_off), ptr(rev_off), ptr(off), int(max_deg_a), ptr(flags),
                                            ptr(wc), cap, ptr(hist), ptr(cnt1), ptr(cnt2), ptr(status),
                                            stream_ptr()), "ocn_cn_walk_flags")
     else:
@@ -163,6 +174,16 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
                                       ptr(cnt1), ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_flags")
     _mark("cn_flags")
     return order, off, flags, wc, hist, cnt1, cnt2, status
+
+
+def neighbor_degree_sum(rowptr: Tensor, col: Tensor) -> Tensor:
+    """nds[v] = Σ_{u∈N(v)} deg(u) (int64): the elements a sweep of v's neighbour rows touches."""
+    _req(rowptr, torch.int64, "rowptr", 1); _req(col, torch.int32, "col", 1)
+    n = rowptr.numel() - 1
+    out = torch.empty(n, dtype=torch.int64, device=rowptr.device)
+    check(_lib.lib().ocn_neighbor_degree_sum(ptr(rowptr), ptr(col), n, ptr(out), stream_ptr()),
+          "ocn_neighbor_degree_sum")
+    return out
 
 
 def cn_weights_cn5(hist: Tensor, innerprod: Tensor, valued: bool = False, wsd=None) -> Tensor:

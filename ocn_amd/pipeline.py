@@ -70,16 +70,21 @@ class TwoStreamScorer:
 
 @torch.no_grad()
 def score_edges(predictor, h: Tensor, adj, adj2, edges: Tensor, batch_size: int, args=None,
-                scorer: Optional[TwoStreamScorer] = None) -> Tensor:
+                scorer: Optional[TwoStreamScorer] = None, run_ahead: int = 6) -> Tensor:
     """Scores for ``edges`` [n, 2] (the layout of ``split_edge[...]['edge']``), batched like
-    ``PermIterator(.., training=False)``; returns a [n] fp32 tensor on the device."""
+    ``PermIterator(.., training=False)``; returns a [n] fp32 tensor on the device.  The host stays at
+    most ``run_ahead`` batches ahead of the GPU: an unbounded backlog makes the HIP runtime block the
+    host until the queue has drained completely, and it bounds the live scratch."""
     if predictor.training:
         raise RuntimeError("score_edges is the eval path; call predictor.eval() first")
     scorer = scorer or TwoStreamScorer(predictor, h.device)
     h = h.contiguous()
     scorer.begin()
-    outs = []
+    outs, done = [], []
     for perm in PermIterator(edges.device, edges.shape[0], batch_size, training=False):
+        if len(done) >= max(run_ahead, 1):
+            done.pop(0).synchronize()
         outs.append(scorer.submit(h, adj, adj2, edges[perm].t().contiguous(), args))
+        done.append(scorer.mlp_stream.record_event())
     scorer.end(outs)
     return torch.cat(outs, dim=0).squeeze(-1) if outs else h.new_zeros(0)

@@ -76,6 +76,7 @@ class SparseTensor:
         self._row_cache: Optional[Tensor] = None
         self._maxdeg: Optional[int] = None
         self._bitmap: Optional[Tensor] = None
+        self._nds: Optional[Tensor] = None
         self.storage = _Storage(self)
 
     # ---- constructors ------------------------------------------------------------------
@@ -149,6 +150,14 @@ class SparseTensor:
         if self._maxdeg is None:
             self._maxdeg = int((self._rowptr[1:] - self._rowptr[:-1]).max()) if self._sizes[0] else 0
         return self._maxdeg
+
+    def neighbor_degree_sum(self) -> Tensor:
+        """Σ_{u∈N(v)} deg(u) per node, cached: lets the walk-count route sweep each candidate edge from
+        its cheaper endpoint (ocn_hip.h: ocn_neighbor_degree_sum).  Square adjacencies only."""
+        if self._nds is None:
+            from . import ops
+            self._nds = ops.neighbor_degree_sum(self._rowptr, self._col)
+        return self._nds
 
     # ---- device movement ---------------------------------------------------------------
     def to_device(self, device, non_blocking: bool = False) -> "SparseTensor":

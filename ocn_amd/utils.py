@@ -67,11 +67,12 @@ class CNState:
         (self.order, self.off, self.flags, self.wc, self.hist, self.cnt1, self.cnt2, self.status) = ops.cn_flags(
             adj._rowptr, adj._col, None if walk else (t1._rowptr, t1._col),
             None if (walk or t2 is None) else (t2._rowptr, t2._col), self.src, self.dst, self.N,
-            adj.max_rowcount(), walk=walk, t2_bitmap=None if (walk or t2 is None) else t2._bitmap, wsd=ws)
+            adj.max_rowcount(), walk=walk, t2_bitmap=None if (walk or t2 is None) else t2._bitmap, wsd=ws,
+            nds=adj.neighbor_degree_sum() if (walk and ops.walk_two_sided) else None)
         self._hist_live = True
 
     def check_status(self) -> None:
-        if int(self.status.item()) != 0:
+        if int(self.status[0].item()) != 0:
             raise RuntimeError("CN flag buffer capacity exceeded")
 
     def hist_counts(self) -> Tensor:

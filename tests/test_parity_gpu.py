@@ -451,6 +451,58 @@ def test_walk_route_counts_values_and_pools(case):
         assert (g2.cpu() - r2).abs().max().item() <= tol * max(1.0, r2.abs().max().item())
 
 
+def _walk_raw(adj, e, nds):
+    from ocn_amd import ops
+    order, off, flags, wc, hist, c1, c2, status = ops.cn_flags(
+        adj._rowptr, adj._col, None, None, e[0].contiguous(), e[1].contiguous(), adj.size(1), adj.max_rowcount(),
+        walk=True, nds=nds)
+    n = int(off[-1])
+    assert int(status[0]) == 0
+    return flags[:n].cpu(), wc[:n].cpu(), ops.hist_counts(hist).cpu(), c1.cpu(), c2.cpu()
+
+
+@pytest.mark.parametrize("hubs", [0, 3])
+def test_walk_route_swept_from_either_endpoint(hiplib, hubs):
+    """cn2[e,k] = #2-walks j -> m -> k can be enumerated from i's rows or from j's rows
+    (ocn_hip.h: ocn_walk_rev_offsets): forward-only, reverse-everywhere (a doctored cost vector) and
+    the cost-based mix give identical flags, walk counts, histograms and per-edge counts — and the mix
+    equals the oracle."""
+    n, B = 6000, 3000
+    oadj = make_graph(n, 9, 300, 11, isolated=20)
+    if hubs:    # hub nodes with thousands of neighbours (beyond the forward sweep's LDS set, within and beyond the reverse one's)
+        g = torch.Generator().manual_seed(5)
+        extra = [torch.stack([torch.full((d,), v), torch.randperm(n, generator=g)[:d]])
+                 for v, d in zip(range(hubs), (5500, 2500, 900))]
+        ei = torch.cat([torch.stack([oadj.row, oadj.col])] + extra, 1)
+        ei = ei[:, ei[0] != ei[1]]
+        oadj = O.to_symmetric(O.from_edge_index(ei, n))
+    e = batch(oadj, B, 77)
+    if hubs:    # hub -> leaf, leaf -> hub and hub -> hub candidates
+        e[:, :40] = torch.stack([torch.arange(40) % hubs, torch.arange(100, 140)])
+        e[:, 40:80] = torch.stack([torch.arange(200, 240), torch.arange(40) % hubs])
+        e[:, 80:83] = torch.tensor([[0, 1, 2], [1, 2, 0]])
+    adj = to_product(oadj, DEV)
+    ed = e.to(DEV)
+    nds = adj.neighbor_degree_sum()
+    deg = oadj.rowcount()
+    assert nds.cpu().tolist() == torch.zeros(n, dtype=torch.long).index_add_(0, oadj.row, deg[oadj.col]).tolist()
+    fwd = _walk_raw(adj, ed, None)
+    mix = _walk_raw(adj, ed, nds)
+    forced = torch.zeros_like(nds); forced[ed[0]] = 1 << 50; forced[ed[1]] = 0     # src rows look expensive, dst rows free
+    forced[ed[0][ed[0] == ed[1]]] = 0
+    rev = _walk_raw(adj, ed, forced)
+    for a, b, c in zip(fwd, mix, rev):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    oc1, oc2 = O.get_cn1_cn2(oadj, e)
+    assert mix[3].tolist() == torch.bincount(oc1.row, minlength=B).tolist()
+    assert mix[4].tolist() == torch.bincount(oc2.row, minlength=B).tolist()
+    assert mix[2][:, 3].tolist() == torch.zeros(n, dtype=torch.long).index_add_(0, oc2.col, oc2.val.long()).tolist()
+    if hubs:    # the cost model does pick the reverse sweep for hub -> leaf candidates
+        i, j = e[0], e[1]
+        picks = (2 * nds.cpu()[j] + 2 * deg[i] * ((deg[j] + 63) // 64) + 2 * deg[i] < nds.cpu()[i])
+        assert picks[:40][i[:40] < 2].all() and not picks[40:80].any()
+
+
 @pytest.mark.parametrize("name", ["cn5", "cn7"])
 def test_walk_route_predictor_scores(case, name):
     from ocn_amd.model import predictor_dict
