@@ -51,10 +51,13 @@ int64_t ocn_order_workspace_bytes(int64_t n_nodes);
 int ocn_order_by_node(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* order, void* workspace,
                       void* stream);
 
-/* Work-item offsets of the walk route: out[slot] = sum over earlier processing slots of
- * ceil(deg_A(src[order[slot]]) / chunk), out[B] = number of items (chunk = ocn_walk_chunk()). */
-int ocn_chunk_offsets(const int64_t* rowptrA, const int64_t* src, const int64_t* order, int64_t B,
-                      int32_t chunk, int64_t* out, void* workspace, void* stream);
+/* Forward work-item offsets of the walk route: out[slot] = number of items of the earlier processing
+ * slots, out[B] = number of items.  A batch row's items are groups of consecutive chunks of
+ * ocn_walk_chunk() neighbours of its source; with nds (ocn_neighbor_degree_sum, or NULL) the group
+ * size adapts so that an item sweeps a bounded number of elements — pass the SAME nds to
+ * ocn_cn_walk_flags. */
+int ocn_chunk_offsets(const int64_t* rowptrA, const int64_t* nds /* or NULL */, const int64_t* src,
+                      const int64_t* order, int64_t B, int64_t* out, void* workspace, void* stream);
 
 /* Exclusive scan of int32 counts into int64 offsets (out[n] = total). */
 int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, void* stream);

@@ -28,7 +28,7 @@ SIGNATURES = {
     "ocn_order_by_node": (c_int32, [_P, c_int64, c_int64, _P, _P, _P]),
     "ocn_cn_flags": (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int64, c_int64, _P, _P, c_int64, _P,
                                _P, _P, _P, _P]),
-    "ocn_chunk_offsets": (c_int32, [_P, _P, _P, c_int64, c_int32, _P, _P, _P]),
+    "ocn_chunk_offsets": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P]),
     "ocn_walk_chunk": (c_int32, []),
     "ocn_cn_walk_flags": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P,
                                     _P, _P]),

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
 // a handful of live lanes on nearly every wave iteration.
 #define WALK_BM_BITS 18
 #define WALK_BM_WORDS (1 << (WALK_BM_BITS - 5))
-#define WALK_Q 2048           /* queue entries; flushed when half full, overflow resolves in place */
+#define WALK_Q 1024           /* queue entries; flushed when half full, overflow resolves in place */
 
 __device__ __forceinline__ unsigned walk_bit(int32_t v) { return ((unsigned)v * 2654435761u) >> (32 - WALK_BM_BITS); }
 __device__ __forceinline__ void walk_bm_add(unsigned* bm, int32_t v) {
@@ -197,54 +197,80 @@ __device__ __forceinline__ i64 sorted_find(const int32_t* __restrict__ a, i64 n,
   return (lo < n && a[lo] == key) ? lo : -1;
 }
 
-// batch slot of a work item: last slot with item_off[slot] <= item
-__device__ __forceinline__ i64 walk_item_slot(const i64* __restrict__ item_off, i64 B, i64 item) {
-  i64 lo = 0, hi = B;
-  while (lo < hi) {
-    const i64 mid = (lo + hi) >> 1;
-    if (item_off[mid + 1] <= item) lo = mid + 1; else hi = mid;
+// batch slot of a work item: last slot with item_off[slot] <= item (item_off[0] = 0 <= item <
+// item_off[B]).  Called by one whole wave: 64 probes per round instead of a dependent chain of
+// log2(B) single loads (2 rounds for B = 2048, 3 for 65 536).
+__device__ __forceinline__ i64 walk_item_slot(const i64* __restrict__ item_off, i64 B, i64 item, int lane) {
+  i64 lo = 0, hi = B;                        // item_off[lo] <= item < item_off[hi]
+  while (hi - lo > 1) {
+    const i64 step = (hi - lo + OCN_WAVE - 1) / OCN_WAVE;
+    const i64 idx = lo + (i64)(lane + 1) * step;
+    const bool le = idx < hi && item_off[idx] <= item;
+    const int c = __popcll(__ballot(le));
+    lo += (i64)c * step;
+    hi = lo + step < hi ? lo + step : hi;
   }
   return lo;
 }
 
-// The rows of one chunk, flattened: wave 0 loads the chunk's row ids / starts and the exclusive
-// prefix of their lengths; element x of the concatenation belongs to the last row t with
-// s_pre[t] <= x (s_pre[n_rows..2*WALK_CHUNK) = INT_MAX).
-__device__ __forceinline__ void walk_chunk_rows(const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
-                                                i64 first, int n_rows, int lane, int* s_pre, i64* s_r0,
-                                                int32_t* s_r, int* s_total) {
+#ifndef OCN_X_WALK_THREADS
+#define OCN_X_WALK_THREADS 512
+#endif
+#define WALK_THREADS OCN_X_WALK_THREADS   /* threads per walk work item */
+#define WALK_WAVES (WALK_THREADS / OCN_WAVE)
+#define WALK_ROWS (WALK_WAVES * WALK_CHUNK)   /* rows a forward item can take: one 64-row chunk per wave */
+
+// The rows of one item, flattened.  Wave w loads the ids / starts / lengths of rows [64w, 64w+64) of
+// the item (`first` = index of the item's first row id in colA) and scans the lengths; after the
+// barrier the chunk totals are folded in, so that element x of the concatenation belongs to the last
+// row t with s_pre[t] <= x (s_pre[n_rows] = INT_MAX).  Returns the number of elements.
+__device__ __forceinline__ int walk_item_rows(const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+                                              i64 first, int n_rows, int* s_pre, i64* s_r0, int32_t* s_r,
+                                              int* s_ctot) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int t = threadIdx.x;                 // WALK_THREADS == WALK_ROWS: one row per thread
   int32_t r = 0;
   i64 r0 = 0, dr = 0;
-  if (lane < n_rows) { r = colA[first + lane]; r0 = rowptrA[r]; dr = rowptrA[r + 1] - r0; }
-  const i64 incl = wave_incl_scan(dr, lane);                 // <= 64 x max degree: far below 2^31
-  s_pre[lane] = lane < n_rows ? (int)(incl - dr) : 0x7fffffff;
-  s_pre[lane + WALK_CHUNK] = 0x7fffffff;
-  s_r[lane] = r; s_r0[lane] = r0;
-  if (lane == OCN_WAVE - 1) *s_total = (int)incl;
+  if (t < n_rows) { r = colA[first + t]; r0 = rowptrA[r]; dr = rowptrA[r + 1] - r0; }
+  const i64 incl = wave_incl_scan(dr, lane);                 // an item's elements stay far below 2^31
+  if (lane == OCN_WAVE - 1) s_ctot[w] = (int)incl;
+  s_r[t] = r; s_r0[t] = r0;
+  __syncthreads();
+  int before = 0, total = 0;
+#pragma unroll
+  for (int q = 0; q < WALK_WAVES; ++q) {
+    const int c = s_ctot[q];
+    if (q < w) before += c;
+    total += c;
+  }
+  s_pre[t] = t < n_rows ? before + (int)(incl - dr) : 0x7fffffff;
+  if (t == 0) s_pre[WALK_ROWS] = 0x7fffffff;
+  __syncthreads();
+  return total;
 }
 
-// One work item of either direction: `rows` = a chunk of <= 64 neighbours of the sweeping endpoint
-// (prepared by walk_chunk_rows), `set_g[0..ds)` = the sorted neighbour row of the other endpoint whose
-// bitmap is in s_bm.  Calls hit(key, row_in_chunk, position_in_set) for every swept element that is
-// a member of the set.
+// One work item of either direction: `rows` = the neighbours of the sweeping endpoint prepared by
+// walk_item_rows, `set_g[0..ds)` = the sorted neighbour row of the other endpoint whose bitmap is in
+// s_bm.  Calls hit(key, row_in_item, position_in_set) for every swept element that is a member of
+// the set.
 template <typename Hit>
 __device__ __forceinline__ void walk_sweep(const int32_t* __restrict__ colA, const unsigned* s_bm, const int* s_pre,
                                            const i64* s_r0, int total, const int32_t* __restrict__ set_g, i64 ds,
-                                           int32_t* s_qk, uint8_t* s_qr, int* s_nq, Hit hit) {
+                                           int32_t* s_qk, uint16_t* s_qr, int* s_nq, Hit hit) {
 #ifndef OCN_X_WALK_WU
 #define OCN_X_WALK_WU 8
 #endif
   constexpr int WU = OCN_X_WALK_WU;          // independent element loads in flight per thread
   int lo = 0;                                // a thread's elements come in increasing x: the row pointer only moves forward
-  for (int x0 = 0; x0 < total; x0 += WU * OCN_BLOCK) {              // workgroup-uniform trip count
+  for (int x0 = 0; x0 < total; x0 += WU * WALK_THREADS) {              // workgroup-uniform trip count
     int row[WU];
     int32_t m[WU];
 #pragma unroll
     for (int u = 0; u < WU; ++u) {
-      const int x = x0 + u * OCN_BLOCK + threadIdx.x;
+      const int x = x0 + u * WALK_THREADS + threadIdx.x;
       m[u] = -1;
       if (x < total) {
-        while (s_pre[lo + 1] <= x) ++lo;     // <= 64 advances over the whole item; s_pre[n_rows..] = INT_MAX
+        while (s_pre[lo + 1] <= x) ++lo;     // <= WALK_ROWS advances over the whole item
         m[u] = colA[s_r0[lo] + (x - s_pre[lo])];
       }
       row[u] = lo;
@@ -253,7 +279,7 @@ __device__ __forceinline__ void walk_sweep(const int32_t* __restrict__ colA, con
     for (int u = 0; u < WU; ++u) {
       if (m[u] >= 0 && walk_bm_maybe(s_bm, m[u])) {
         const int q = atomicAdd(s_nq, 1);
-        if (q < WALK_Q) { s_qk[q] = m[u]; s_qr[q] = (uint8_t)row[u]; }
+        if (q < WALK_Q) { s_qk[q] = m[u]; s_qr[q] = (uint16_t)row[u]; }
         else {                                                      // queue full (dense overlap): resolve in place
           const i64 pos = sorted_find(set_g, ds, m[u]);
           if (pos >= 0) hit(m[u], row[u], pos);
@@ -261,9 +287,9 @@ __device__ __forceinline__ void walk_sweep(const int32_t* __restrict__ colA, con
       }
     }
     __syncthreads();
-    if (*s_nq > WALK_Q / 2 || x0 + WU * OCN_BLOCK >= total) {
+    if (*s_nq > WALK_Q / 2 || x0 + WU * WALK_THREADS >= total) {
       const int nq = *s_nq < WALK_Q ? *s_nq : WALK_Q;
-      for (int q = threadIdx.x; q < nq; q += OCN_BLOCK) {
+      for (int q = threadIdx.x; q < nq; q += WALK_THREADS) {
         const i64 pos = sorted_find(set_g, ds, s_qk[q]);
         if (pos >= 0) hit(s_qk[q], (int)s_qr[q], pos);
       }
@@ -274,137 +300,129 @@ __device__ __forceinline__ void walk_sweep(const int32_t* __restrict__ colA, con
   }
 }
 
+#define WALK_SHARED                                     \
+  __shared__ unsigned s_bm[WALK_BM_WORDS];              \
+  __shared__ int s_pre[WALK_ROWS + 1];                  \
+  __shared__ i64 s_r0[WALK_ROWS];                       \
+  __shared__ int32_t s_r[WALK_ROWS];                    \
+  __shared__ int s_ctot[WALK_WAVES];                    \
+  __shared__ int32_t s_qk[WALK_Q];                      \
+  __shared__ uint16_t s_qr[WALK_Q];                     \
+  __shared__ int s_nq;                                  \
+  __shared__ i64 s_slot, s_item
+
+// draw the next work item (ticket counter) and find its batch slot, while the other waves clear the bitmap
+#define WALK_NEXT_ITEM(TICKET, ITEM_OFF)                                                             \
+  if (w == 0) {                                                                                      \
+    i64 t = 0;                                                                                       \
+    if (lane == 0) t = atomicAdd((TICKET), 1);                                                       \
+    t = __shfl(t, 0, OCN_WAVE);                                                                      \
+    const i64 sl = t < n_items ? walk_item_slot((ITEM_OFF), B, t, lane) : 0;                         \
+    if (lane == 0) { s_item = t; s_slot = sl; s_nq = 0; }                                            \
+  } else {                                                                                           \
+    for (int q = threadIdx.x - OCN_WAVE; q < WALK_BM_WORDS; q += WALK_THREADS - OCN_WAVE) s_bm[q] = 0u; \
+  }                                                                                                  \
+  __syncthreads();                                                                                   \
+  const i64 item = s_item;                                                                           \
+  if (item >= n_items) break;                                                                        \
+  const i64 slot = s_slot;                                                                           \
+  const i64 e = order ? order[slot] : slot;                                                          \
+  const i64 i = src[e], j = dst[e];                                                                  \
+  const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;                                               \
+  const i64 b0 = rowptrA[j], db = rowptrA[j + 1] - b0;                                               \
+  const i64 base = off[e]
+
 // Reverse sweep (runs first, only for the batch rows walk_reverse() selects): work item = (batch row,
-// chunk of WALK_CHUNK neighbours m of j).  The members k' of the rows N(m) are probed against N(i);
-// a hit adds one walk to wc[off[e] + position of k' in N(i)] (wc is zero on entry).  The forward
-// kernel's items of that batch row then only finalise it.
-__global__ __launch_bounds__(OCN_BLOCK) void cn_walk_rev_kernel(
+// chunk of WALK_REV_CHUNK neighbours m of j).  The members k' of the rows N(m) are probed against
+// N(i); a hit adds one walk to wc[off[e] + position of k' in N(i)] (wc is zero on entry).  The forward
+// kernel's items of that batch row then only finalise it.  Items differ 100x in cost: workgroups draw
+// them from a ticket counter.
+__global__ __launch_bounds__(WALK_THREADS) void cn_walk_rev_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     const i64* __restrict__ rev_off, const i64* __restrict__ off, int32_t* __restrict__ wc, i64 cap,
     int32_t* __restrict__ ticket) {
-  __shared__ unsigned s_bm[WALK_BM_WORDS];
-  __shared__ int s_pre[2 * WALK_CHUNK];
-  __shared__ i64 s_m0[WALK_CHUNK];
-  __shared__ int32_t s_m[WALK_CHUNK];
-  __shared__ int32_t s_qk[WALK_Q];
-  __shared__ uint8_t s_qr[WALK_Q];
-  __shared__ int s_nq;
-  __shared__ i64 s_slot, s_item;
-  __shared__ int s_total;
+  WALK_SHARED;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const i64 n_items = rev_off[B];
-  for (;;) {                                   // items differ 100x in cost: workgroups draw them from a ticket counter
-    if (threadIdx.x == 0) {
-      s_item = atomicAdd(ticket, 1);
-      if (s_item < n_items) s_slot = walk_item_slot(rev_off, B, s_item);
-      s_nq = 0;
-    }
-    for (int q = threadIdx.x; q < WALK_BM_WORDS; q += OCN_BLOCK) s_bm[q] = 0u;
-    __syncthreads();
-    const i64 item = s_item;
-    if (item >= n_items) break;
-    const i64 slot = s_slot;
-    const i64 e = order ? order[slot] : slot;
-    const i64 i = src[e], j = dst[e];
-    const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
-    const i64 b0 = rowptrA[j], db = rowptrA[j + 1] - b0;
-    const i64 base = off[e];
-    const i64 p_lo = (item - rev_off[slot]) * WALK_CHUNK;
-    const int nm = (int)(((p_lo + WALK_CHUNK) < db ? (p_lo + WALK_CHUNK) : db) - p_lo);
+  for (;;) {
+    WALK_NEXT_ITEM(ticket, rev_off);
+    const i64 p_lo = (item - rev_off[slot]) * WALK_REV_CHUNK;
+    const int nm = (int)(((p_lo + WALK_REV_CHUNK) < db ? (p_lo + WALK_REV_CHUNK) : db) - p_lo);
     const int32_t* ni_g = colA + a0;
-    if (w == 0) {
-      walk_chunk_rows(rowptrA, colA, b0 + p_lo, nm, lane, s_pre, s_m0, s_m, &s_total);
-    } else {
-      for (i64 q = threadIdx.x - OCN_WAVE; q < da; q += OCN_BLOCK - OCN_WAVE) walk_bm_add(s_bm, ni_g[q]);
-    }
-    __syncthreads();
+    for (i64 q = threadIdx.x; q < da; q += WALK_THREADS) walk_bm_add(s_bm, ni_g[q]);
+    int total = walk_item_rows(rowptrA, colA, b0 + p_lo, nm, s_pre, s_r0, s_r, s_ctot);
 #ifdef OCN_X_WALK_NOSWEEP   /* timing experiment: per-item overhead only */
-    const int total = 0;
-#else
-    const int total = base + da <= cap ? s_total : 0;
+    total = 0;
 #endif
+    if (base + da > cap) total = 0;
     int32_t* wrow = wc + base;
-    walk_sweep(colA, s_bm, s_pre, s_m0, total, ni_g, da, s_qk, s_qr, &s_nq,
+    walk_sweep(colA, s_bm, s_pre, s_r0, total, ni_g, da, s_qk, s_qr, &s_nq,
                [wrow](int32_t, int, i64 pos) { atomicAdd(wrow + pos, 1); });
     __syncthreads();
   }
 }
 
-// Forward sweep.  Work item = (batch row, chunk of WALK_CHUNK neighbours k of i); items are enumerated
-// through the exclusive scan chunk_off[] so that a hub source node is spread over many workgroups
-// instead of serialising one.  The members of the chunk's rows N(k) are FLATTENED: the 256 threads
+// Forward sweep.  Work item = (batch row, group of <= WALK_WAVES consecutive 64-row chunks of N(i));
+// items are enumerated through the exclusive scan chunk_off[] so that a hub source node is spread
+// over many workgroups instead of serialising one, while a light row is a single item (one round of
+// dependent loads for all its rows).  The members of the item's rows N(k) are FLATTENED: the threads
 // sweep the concatenation of the rows, so short rows do not idle lanes, no load waits on a per-row
 // pointer chase, and a hub k costs what its length costs; each is probed against N(j), and a hit
 // bumps the row's counter with an LDS atomic.  For a batch row the reverse sweep has already counted
 // (walk_reverse()), the item only reads its counts back from wc and finalises flags, histogram and
 // per-edge counts.
-__global__ __launch_bounds__(OCN_BLOCK) void cn_walk_kernel(
+__global__ __launch_bounds__(WALK_THREADS) void cn_walk_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA, const i64* __restrict__ nds,
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     const i64* __restrict__ chunk_off, const i64* __restrict__ off, uint8_t* __restrict__ flags,
     int32_t* __restrict__ wc, i64 cap, u64* __restrict__ hist, int32_t* __restrict__ cnt1,
     int32_t* __restrict__ cnt2, int32_t* __restrict__ status) {   // status[0] flags, [1] / [2] item tickets (zero on entry)
-  __shared__ unsigned s_bm[WALK_BM_WORDS];
-  __shared__ int s_pre[2 * WALK_CHUNK];      // exclusive prefix of the chunk's row lengths; [nk..] = INT_MAX
-  __shared__ i64 s_k0[WALK_CHUNK];
-  __shared__ int32_t s_k[WALK_CHUNK];
-  __shared__ int s_walks[WALK_CHUNK];
-  __shared__ int32_t s_qk[WALK_Q];
-  __shared__ uint8_t s_qr[WALK_Q];
-  __shared__ int s_nq;
-  __shared__ i64 s_slot, s_item;
-  __shared__ int s_total;
+  WALK_SHARED;
+  __shared__ int s_walks[WALK_ROWS];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (blockIdx.x == 0 && threadIdx.x == 0 && off[B] > cap) atomicOr(status, 1);
   const i64 n_items = chunk_off[B];
   for (;;) {
-    if (threadIdx.x == 0) {
-      s_item = atomicAdd(status + 1, 1);
-      if (s_item < n_items) s_slot = walk_item_slot(chunk_off, B, s_item);
-      s_nq = 0;
-    }
-    for (int q = threadIdx.x; q < WALK_BM_WORDS; q += OCN_BLOCK) s_bm[q] = 0u;
-    __syncthreads();
-    const i64 item = s_item;
-    if (item >= n_items) break;
-    const i64 slot = s_slot;
-    const i64 e = order ? order[slot] : slot;
-    const i64 i = src[e], j = dst[e];
-    const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
-    const i64 b0 = rowptrA[j], db = rowptrA[j + 1] - b0;
-    const i64 base = off[e];
-    const i64 p_lo = (item - chunk_off[slot]) * WALK_CHUNK;
-    const int nk = (int)(((p_lo + WALK_CHUNK) < da ? (p_lo + WALK_CHUNK) : da) - p_lo);
+    WALK_NEXT_ITEM(status + 1, chunk_off);
     const bool rev = walk_reverse(nds, i, j, da, db);      // workgroup-uniform
     const int32_t* nj_g = colA + b0;
-    if (w == 0) {                              // the chunk's rows: ids, starts, prefix sums of lengths
-      walk_chunk_rows(rowptrA, colA, a0 + p_lo, nk, lane, s_pre, s_k0, s_k, &s_total);
-      s_walks[lane] = 0;
-    } else {                                   // meanwhile the other waves set N(j)'s bits
-      for (i64 q = threadIdx.x - OCN_WAVE; q < db; q += OCN_BLOCK - OCN_WAVE) walk_bm_add(s_bm, nj_g[q]);
-    }
-    __syncthreads();
-#ifdef OCN_X_WALK_NOSWEEP
-    const int total = 0;
-#else
-    const int total = rev ? 0 : s_total;
+#ifndef OCN_X_WALK_NOBM
+    for (i64 q = threadIdx.x; q < db; q += WALK_THREADS) walk_bm_add(s_bm, nj_g[q]);
 #endif
+    const i64 n_chunks = (da + WALK_CHUNK - 1) / WALK_CHUNK;
+    const i64 cg = walk_group(nds, i, da);
+    const i64 p_lo = (item - chunk_off[slot]) * cg * WALK_CHUNK;
+    const i64 p_hi = p_lo + cg * WALK_CHUNK < da ? p_lo + cg * WALK_CHUNK : da;
+    (void)n_chunks;
+    const int nk = (int)(p_hi - p_lo);
+    const bool in_cap = base + da <= cap;
+    s_walks[threadIdx.x] = 0;
+#ifdef OCN_X_WALK_NOROWS
+    int total = 0; __syncthreads();
+#else
+    int total = walk_item_rows(rowptrA, colA, a0 + p_lo, nk, s_pre, s_r0, s_r, s_ctot);
+#endif
+#ifdef OCN_X_WALK_NOSWEEP
+    total = 0;
+#endif
+    if (rev) total = 0;
     int* walks_of = s_walks;
-    walk_sweep(colA, s_bm, s_pre, s_k0, total, nj_g, db, s_qk, s_qr, &s_nq,
+    walk_sweep(colA, s_bm, s_pre, s_r0, total, nj_g, db, s_qk, s_qr, &s_nq,
                [walks_of](int32_t, int row, i64) { atomicAdd(walks_of + row, 1); });
     __syncthreads();
-    if (w == 0) {
+#ifndef OCN_X_WALK_NOFIN
+    {                                          // finalise: one row per thread
+      const int t = threadIdx.x;
       bool f1 = false, f2 = false;
-      if (lane < nk) {
-        const int32_t k = s_k[lane];
-        const bool in_cap = base + da <= cap;
-        const int walks = rev ? (in_cap ? wc[base + p_lo + lane] : 0) : s_walks[lane];
+      if (t < nk) {
+        const int32_t k = s_r[t];
+        const int walks = rev ? (in_cap ? wc[base + p_lo + t] : 0) : s_walks[t];
         f1 = walk_bm_maybe(s_bm, k) && sorted_has(nj_g, db, k);
         f2 = walks > 0;
         if (in_cap) {
-          flags[base + p_lo + lane] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
-          if (!rev) wc[base + p_lo + lane] = walks;
+          flags[base + p_lo + t] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
+          if (!rev) wc[base + p_lo + t] = walks;
         }
         if (f1 | f2) {
           atomicAdd(hist + 2 * (i64)k, (u64)f1 | ((u64)f2 << HF_BITS) | (1ull << (2 * HF_BITS)));
@@ -412,11 +430,12 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_walk_kernel(
         }
       }
       const int c1 = __popcll(__ballot(f1)), c2 = __popcll(__ballot(f2));
-      if (lane == 0) {                         // cnt1 / cnt2 are zero on entry; a row may span several items
+      if (lane == 0) {                         // cnt1 / cnt2 are zero on entry; a row spans several waves and items
         if (c1) atomicAdd(cnt1 + e, c1);
         if (c2) atomicAdd(cnt2 + e, c2);
       }
     }
+#endif
     __syncthreads();
   }
 }
@@ -543,13 +562,12 @@ __device__ __forceinline__ void entry_weights(unsigned f, const float4& w, float
 // Pool the flagged neighbours at positions [p_begin, p_end) of the source row into acc1 / acc2, in
 // ascending position (= column) order.  LPE lanes cooperate; each lane owns NV float4 of the
 // H = LPE*NV*4 features; four embedding rows are in flight per group.
-template <int LPE, int NV>
+template <int LPE, int NV, int UNR = 4>
 __device__ __forceinline__ void pool_range(i64 p_begin, i64 p_end, i64 a0, i64 base, int gl, int gbase,
                                            const int32_t* __restrict__ colA, const uint8_t* __restrict__ flags,
                                            const int32_t* __restrict__ wc, const float4* __restrict__ weights,
                                            const float4* __restrict__ h4, i64 rowq, float4 (&acc1)[NV],
                                            float4 (&acc2)[NV]) {
-  constexpr int UNR = 4;
   // Narrow groups (small H) would otherwise pay one dependent load chain (column id -> column weights)
   // per LPE positions: a lane fetches PT positions per round, so a round always covers 64 of them.
   constexpr int PT = (OCN_WAVE / LPE) < 8 ? (OCN_WAVE / LPE) : 8;
@@ -673,6 +691,103 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
   pool_store<LPE, NV>(e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
 }
 
+// position of the n-th (0-based) set bit of m; n < popcount(m)
+__device__ __forceinline__ int select_bit64(unsigned long long m, int n) {
+  int pos = 0;
+#pragma unroll
+  for (int w = 32; w > 0; w >>= 1) {
+    const int c = __popcll(m & ((1ull << w) - 1ull));
+    if (n >= c) { n -= c; m >>= w; pos += w; }
+  }
+  return pos;
+}
+
+// Small batches of narrow embeddings (ppa / citation2: B = 2048, H = 32..64) leave the packed kernel
+// above with a few hundred waves, each lane group walking its row 4 gathers at a time.  Here ONE WAVE
+// takes one batch row: the 64/LPE lane groups fetch different neighbours' embedding rows (4 x 64/LPE
+// rows in flight), and every group then accumulates all of them in ascending position order (rows
+// handed round by wave shuffle) — the same sequential fp32 sum as the packed kernel, bit for bit.
+template <int LPE, int NV>
+__global__ __launch_bounds__(OCN_BLOCK) void cn_gather_wave_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
+    const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
+    const float4* __restrict__ weights, const float* __restrict__ h, int H,
+    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
+  constexpr int G = OCN_WAVE / LPE;
+  constexpr int UNR = 4;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane % LPE, g = lane / LPE;
+  const i64 slot = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6);
+  if (slot >= B) return;                    // whole wave leaves together
+  const i64 e = order ? order[slot] : slot;
+  const i64 i = src[e], j = dst[e];
+  const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+  if (da > LONG_ROW) return;                // cn_gather_long_kernel's
+  const i64 base = off[e];
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  const i64 rowq = H >> 2;
+  float4 acc1[NV], acc2[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (i64 p0 = 0; p0 < da; p0 += OCN_WAVE) {
+    const i64 p = p0 + lane;
+    int32_t k = 0;
+    unsigned f = 0;
+    int32_t cv = 1;
+    if (p < da) {
+      k = colA[a0 + p]; f = flags[base + p];
+      if (wc) cv = wc[base + p];
+    }
+    float wa = 0.f, wb = 0.f;
+    if (f) entry_weights(f, weights[k], (float)cv, wa, wb);
+    const unsigned long long m = __ballot((wa != 0.f) | (wb != 0.f));
+    const int n = __popcll(m);
+    if (n == 0) continue;
+    // compaction: lane r takes the entry of rank r
+    const int sl = lane < n ? select_bit64(m, lane) : 0;
+    const int32_t kc = __shfl(k, sl, OCN_WAVE);
+    const float wac = __shfl(wa, sl, OCN_WAVE), wbc = __shfl(wb, sl, OCN_WAVE);
+    for (int r0 = 0; r0 < n; r0 += G * UNR) {
+      float4 x[UNR][NV];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int r = r0 + u * G + g;
+        const int32_t kk = __shfl(kc, r & 63, OCN_WAVE);
+        if (r < n) {
+          const float4* row = h4 + (i64)kk * rowq + gl;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) x[u][v] = row[v * LPE];
+        } else {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) x[u][v] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg) {
+          const int r = r0 + u * G + gg;     // wave-uniform
+          if (r < n) {
+            const float war = __shfl(wac, r, OCN_WAVE), wbr = __shfl(wbc, r, OCN_WAVE);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+              float4 xs;
+              xs.x = __shfl(x[u][v].x, gg * LPE + gl, OCN_WAVE);
+              xs.y = __shfl(x[u][v].y, gg * LPE + gl, OCN_WAVE);
+              xs.z = __shfl(x[u][v].z, gg * LPE + gl, OCN_WAVE);
+              xs.w = __shfl(x[u][v].w, gg * LPE + gl, OCN_WAVE);
+              axpy4(acc1[v], war, xs);
+              axpy4(acc2[v], wbr, xs);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (g == 0) pool_store<LPE, NV>(e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
+}
+
 // One workgroup per batch row whose source row is longer than LONG_ROW (hub sources): the 256/LPE
 // lane groups pool contiguous segments, partial sums meet in LDS and are added in segment order.
 template <int LPE, int NV>
@@ -701,7 +816,9 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_long_kernel(
   float4 acc1[NV], acc2[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  pool_range<LPE, NV>(pb, pe, a0, off[e], gl, gbase, colA, flags, wc, weights, h4, rowq, acc1, acc2);
+  // hub rows are few and long: more gathers in flight per lane group where the registers allow
+  pool_range<LPE, NV, (LPE * NV <= 16 ? 16 : (LPE * NV <= 32 ? 8 : 4))>(pb, pe, a0, off[e], gl, gbase, colA, flags, wc,
+                                                                       weights, h4, rowq, acc1, acc2);
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     s_part[g][0][gl + v * LPE] = acc1[v];
@@ -909,12 +1026,12 @@ int ocn_cn_walk_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t
   if (nds && flags_cap > 0) {
     hipLaunchKernelGGL(walk_zero_kernel, dim3(grid_for((flags_cap + OCN_BLOCK - 1) / OCN_BLOCK, 2048)),
                        dim3(OCN_BLOCK), 0, st, (const i64*)off, (i64)B, (i64)flags_cap, wc);
-    hipLaunchKernelGGL(cn_walk_rev_kernel, dim3(grid), dim3(OCN_BLOCK), 0, st,
+    hipLaunchKernelGGL(cn_walk_rev_kernel, dim3(grid), dim3(WALK_THREADS), 0, st,
                        (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B,
                        (const i64*)rev_off, (const i64*)off, wc, (i64)flags_cap, status + 2);
   }
-  hipLaunchKernelGGL(cn_walk_kernel, dim3(grid), dim3(OCN_BLOCK), 0, st,
-                     (const i64*)rowptrA, colA, (const i64*)(flags_cap > 0 ? nds : nullptr), (const i64*)src,
+  hipLaunchKernelGGL(cn_walk_kernel, dim3(grid), dim3(WALK_THREADS), 0, st,
+                     (const i64*)rowptrA, colA, (const i64*)nds, (const i64*)src,
                      (const i64*)dst, (const i64*)order, (i64)B, (const i64*)chunk_off, (const i64*)off, flags, wc,
                      (i64)flags_cap, (u64*)hist, cnt1, cnt2, status);
   return launch_status();
@@ -957,8 +1074,12 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream) 
 #define LAUNCH_GATHER(LPE, NV)                                                                      \
   do {                                                                                              \
     const i64 epb = (i64)OCN_WPB * (OCN_WAVE / (LPE));                                              \
-    hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)),          \
-                       dim3(OCN_BLOCK), 0, st, GATHER_ARGS);                                        \
+    if ((LPE) <= 16 && B * (LPE) < 262144) /* the packed form would not fill the SIMDs */            \
+      hipLaunchKernelGGL((cn_gather_wave_kernel<LPE, NV>), dim3((unsigned)((B + OCN_WPB - 1) / OCN_WPB)), \
+                         dim3(OCN_BLOCK), 0, st, GATHER_ARGS);                                      \
+    else                                                                                            \
+      hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)),        \
+                         dim3(OCN_BLOCK), 0, st, GATHER_ARGS);                                      \
     if (max_row_len > LONG_ROW)                                                                     \
       hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV>), dim3((unsigned)B), dim3(OCN_BLOCK), 0,   \
                          st, (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B,   \

@@ -64,11 +64,27 @@ __device__ __forceinline__ i64 block_excl_scan(i64 v, i64* sh, i64* total) {
 // m in N(j) (nds[j] probes against N(i); its hits land through global atomics, each 64-chunk of N(j)
 // sets up N(i)'s bitmap again, and the row is finalised by the forward kernel's items afterwards).
 // A hub source with a modest target is 10-100x cheaper from the target's side.
-#define WALK_CHUNK 64        /* rows (neighbours) per work item, either direction */
+#define WALK_CHUNK 64        /* rows (neighbours of i) per forward work item */
+#define WALK_REV_CHUNK 16    /* rows (neighbours of j) per reverse work item: few items, so finer ones */
+// Forward work items take `walk_group()` consecutive 64-row chunks of the source row, so that an item
+// sweeps about WALK_ITEM_ELEMS elements: a light row (most of a batch) is one item instead of one per
+// 64 neighbours — the per-item set-up (ticket, slot search, row pointers, N(j) bitmap) is what such
+// items cost — while a hub row still spreads over many workgroups.
+#define WALK_ITEM_ELEMS 16384
+#define WALK_GROUP_MAX 8      /* chunks per forward item: one per wave of the 512-thread workgroup */
+__device__ __forceinline__ i64 walk_group(const i64* __restrict__ nds, i64 i, i64 di) {
+  const i64 chunks = (di + WALK_CHUNK - 1) / WALK_CHUNK;
+  if (!nds || chunks <= 1) return 1;
+  const i64 per_chunk = nds[i] / chunks + 1;
+  i64 cg = WALK_ITEM_ELEMS / per_chunk;
+  if (cg > WALK_GROUP_MAX) cg = WALK_GROUP_MAX;
+  return cg < 1 ? 1 : (cg > chunks ? chunks : cg);
+}
+
 __device__ __forceinline__ bool walk_reverse(const i64* __restrict__ nds, i64 i, i64 j, i64 di, i64 dj) {
   if (!nds || dj == 0 || di == 0) return false;
-  const i64 chunks_j = (dj + WALK_CHUNK - 1) / WALK_CHUNK;
-  const i64 rev = 2 * nds[j] + 2 * di * chunks_j + 2 * di;
+  const i64 chunks_j = (dj + WALK_REV_CHUNK - 1) / WALK_REV_CHUNK;
+  const i64 rev = 2 * nds[j] + di * chunks_j + 2 * di;
   return rev < nds[i];
 }
 

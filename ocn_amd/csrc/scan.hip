@@ -15,14 +15,17 @@ struct DegOfSrc {
     return rowptr[i + 1] - rowptr[i];
   }
 };
-struct ChunksOfSlot {      // ceil(deg(src[order[slot]]) / chunk): work items of a batch row, in processing order
+struct ChunksOfSlot {      // forward work items of a batch row, in processing order: groups of walk_group() 64-row chunks
   const i64* rowptr;
+  const i64* nds;
   const i64* src;
   const i64* order;
-  i64 chunk;
   __device__ __forceinline__ i64 operator()(i64 slot) const {
     const i64 i = src[order ? order[slot] : slot];
-    return (rowptr[i + 1] - rowptr[i] + chunk - 1) / chunk;
+    const i64 di = rowptr[i + 1] - rowptr[i];
+    const i64 chunks = (di + WALK_CHUNK - 1) / WALK_CHUNK;
+    const i64 cg = walk_group(nds, i, di);
+    return (chunks + cg - 1) / cg;
   }
 };
 struct RevChunksOfSlot {   // reverse-sweep work items of a batch row: ceil(deg(dst) / chunk) where walk_reverse(), else 0
@@ -35,7 +38,7 @@ struct RevChunksOfSlot {   // reverse-sweep work items of a batch row: ceil(deg(
     const i64 e = order ? order[slot] : slot;
     const i64 i = src[e], j = dst[e];
     const i64 di = rowptr[i + 1] - rowptr[i], dj = rowptr[j + 1] - rowptr[j];
-    return walk_reverse(nds, i, j, di, dj) ? (dj + WALK_CHUNK - 1) / WALK_CHUNK : 0;
+    return walk_reverse(nds, i, j, di, dj) ? (dj + WALK_REV_CHUNK - 1) / WALK_REV_CHUNK : 0;
   }
 };
 struct I32In {
@@ -103,9 +106,42 @@ __global__ __launch_bounds__(OCN_BLOCK) void scan_apply(Op op, i64 n, const i64*
   if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_sum[nt];
 }
 
+// small inputs (a ppa / citation2 batch has 2048 rows): the whole scan in one workgroup, one launch
+#define SCAN_SINGLE_MAX (8 * SCAN_TILE)
+template <typename Op>
+__global__ __launch_bounds__(OCN_BLOCK) void scan_single(Op op, i64 n, i64* out) {
+  __shared__ i64 sh[2 * OCN_WPB];
+  i64 carry = 0;
+  for (i64 t0 = 0; t0 < n; t0 += SCAN_TILE) {
+    const i64 base = t0 + (i64)threadIdx.x * SCAN_IPT;
+    i64 v[SCAN_IPT];
+    i64 s = 0;
+#pragma unroll
+    for (int t = 0; t < SCAN_IPT; ++t) {
+      const i64 e = base + t;
+      v[t] = e < n ? op(e) : 0;
+      s += v[t];
+    }
+    i64 tot;
+    i64 ex = carry + block_excl_scan(s, sh, &tot);
+#pragma unroll
+    for (int t = 0; t < SCAN_IPT; ++t) {
+      const i64 e = base + t;
+      if (e < n) out[e] = ex;
+      ex += v[t];
+    }
+    carry += tot;
+  }
+  if (threadIdx.x == 0) out[n] = carry;
+}
+
 template <typename Op>
 static int run_scan(Op op, i64 n, i64* out, void* ws, hipStream_t st) {
   if (n < 0 || !out || !ws) return OCN_EINVAL;
+  if (n <= SCAN_SINGLE_MAX) {
+    hipLaunchKernelGGL(scan_single<Op>, dim3(1), dim3(OCN_BLOCK), 0, st, op, n, out);
+    return launch_status();
+  }
   i64 nt = (n + SCAN_TILE - 1) / SCAN_TILE;
   if (nt == 0) nt = 1;
   i64* tile_sum = (i64*)ws;
@@ -179,10 +215,10 @@ int ocn_edge_offsets(const int64_t* rowptrA, const int64_t* src, int64_t B, int6
   return run_scan(op, B, (i64*)off, workspace, (hipStream_t)stream);
 }
 
-int ocn_chunk_offsets(const int64_t* rowptrA, const int64_t* src, const int64_t* order, int64_t B,
-                      int32_t chunk, int64_t* out, void* workspace, void* stream) {
-  if (!rowptrA || (!src && B > 0) || chunk <= 0) return OCN_EINVAL;
-  ChunksOfSlot op{(const i64*)rowptrA, (const i64*)src, (const i64*)order, (i64)chunk};
+int ocn_chunk_offsets(const int64_t* rowptrA, const int64_t* nds, const int64_t* src, const int64_t* order,
+                      int64_t B, int64_t* out, void* workspace, void* stream) {
+  if (!rowptrA || (!src && B > 0)) return OCN_EINVAL;
+  ChunksOfSlot op{(const i64*)rowptrA, (const i64*)nds, (const i64*)src, (const i64*)order};
   return run_scan(op, B, (i64*)out, workspace, (hipStream_t)stream);
 }
 

@@ -142,19 +142,20 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     cnt2 = buf(wsd, "cnt2", B, torch.int32, dev, zero=walk) if (walk or t2 is not None) else None
     chunk_off = rev_off = None
     if walk:
-        chunk_off = buf(wsd, "chunk_off", B + 1, torch.int64, dev)
-        cws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, dev)
-        check(_lib.lib().ocn_chunk_offsets(ptr(rowptrA), ptr(src), ptr(order), B, _lib.lib().ocn_walk_chunk(),
-                                           ptr(chunk_off), ptr(cws), stream_ptr()), "ocn_chunk_offsets")
         if nds is not None and walk_two_sided:
             _req(nds, torch.int64, "nds", 1)
             if nds.numel() != rowptrA.numel() - 1:
                 raise ValueError("nds does not match the adjacency")
+        else:
+            nds = None
+        chunk_off = buf(wsd, "chunk_off", B + 1, torch.int64, dev)
+        cws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, dev)
+        check(_lib.lib().ocn_chunk_offsets(ptr(rowptrA), ptr(nds), ptr(src), ptr(order), B, ptr(chunk_off), ptr(cws),
+                                           stream_ptr()), "ocn_chunk_offsets")
+        if nds is not None:
             rev_off = buf(wsd, "rev_off", B + 1, torch.int64, dev)
             check(_lib.lib().ocn_walk_rev_offsets(ptr(rowptrA), ptr(nds), ptr(src), ptr(dst), ptr(order), B,
                                                   ptr(rev_off), ptr(cws), stream_ptr()), "ocn_walk_rev_offsets")
-        else:
-            nds = None
     status = buf(wsd, "status", 4, torch.int32, dev, zero=True)     # [0] overflow flag; [1], [2] walk-route work tickets
     _mark("cn_prep")
     if walk:

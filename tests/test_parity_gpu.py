@@ -499,7 +499,7 @@ def test_walk_route_swept_from_either_endpoint(hiplib, hubs):
     assert mix[2][:, 3].tolist() == torch.zeros(n, dtype=torch.long).index_add_(0, oc2.col, oc2.val.long()).tolist()
     if hubs:    # the cost model does pick the reverse sweep for hub -> leaf candidates
         i, j = e[0], e[1]
-        picks = (2 * nds.cpu()[j] + 2 * deg[i] * ((deg[j] + 63) // 64) + 2 * deg[i] < nds.cpu()[i])
+        picks = (2 * nds.cpu()[j] + deg[i] * ((deg[j] + 15) // 16) + 2 * deg[i] < nds.cpu()[i])
         assert picks[:40][i[:40] < 2].all() and not picks[40:80].any()
 
 
