@@ -691,22 +691,12 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
   pool_store<LPE, NV>(e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
 }
 
-// position of the n-th (0-based) set bit of m; n < popcount(m)
-__device__ __forceinline__ int select_bit64(unsigned long long m, int n) {
-  int pos = 0;
-#pragma unroll
-  for (int w = 32; w > 0; w >>= 1) {
-    const int c = __popcll(m & ((1ull << w) - 1ull));
-    if (n >= c) { n -= c; m >>= w; pos += w; }
-  }
-  return pos;
-}
-
 // Small batches of narrow embeddings (ppa / citation2: B = 2048, H = 32..64) leave the packed kernel
 // above with a few hundred waves, each lane group walking its row 4 gathers at a time.  Here ONE WAVE
-// takes one batch row: the 64/LPE lane groups fetch different neighbours' embedding rows (4 x 64/LPE
-// rows in flight), and every group then accumulates all of them in ascending position order (rows
-// handed round by wave shuffle) — the same sequential fp32 sum as the packed kernel, bit for bit.
+// takes one batch row: per round of 64 positions the live entries are compacted (rank = position among
+// the live ones), the 64/LPE lane groups fetch all their embedding rows at once (up to 64 gathers in
+// flight per wave) into the wave's LDS slab, and lane group 0 accumulates them in rank order — the
+// same sequential ascending-column fp32 sum as the packed kernel, bit for bit.
 template <int LPE, int NV>
 __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_wave_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
@@ -715,11 +705,14 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_wave_kernel(
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
     float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
   constexpr int G = OCN_WAVE / LPE;
-  constexpr int UNR = 4;
-  const int lane = threadIdx.x & 63;
+  constexpr int UNR = LPE;                  // G * UNR = 64 rows: a whole round in flight
+  __shared__ float4 s_x[OCN_WPB][OCN_WAVE][LPE * NV];
+  __shared__ int32_t s_k[OCN_WPB][OCN_WAVE];
+  __shared__ float2 s_w[OCN_WPB][OCN_WAVE];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int gl = lane % LPE, g = lane / LPE;
-  const i64 slot = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6);
-  if (slot >= B) return;                    // whole wave leaves together
+  const i64 slot = (i64)blockIdx.x * OCN_WPB + wv;
+  if (slot >= B) return;                    // whole wave leaves together (no workgroup barriers below)
   const i64 e = order ? order[slot] : slot;
   const i64 i = src[e], j = dst[e];
   const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
@@ -730,74 +723,86 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_wave_kernel(
   float4 acc1[NV], acc2[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Software pipeline over the 64-position rounds: a round needs column id -> column weights -> rows,
+  // three dependent trips to memory; the ids of round r+2 and the weights of round r+1 are requested
+  // before round r's rows are gathered.
+  int32_t k_n = 0, k_nn = 0, cv_n = 1, cv_nn = 1;
+  unsigned f_n = 0, f_nn = 0;
+  if (lane < da) { k_n = colA[a0 + lane]; f_n = flags[base + lane]; if (wc) cv_n = wc[base + lane]; }
+  if (OCN_WAVE + lane < da) {
+    k_nn = colA[a0 + OCN_WAVE + lane]; f_nn = flags[base + OCN_WAVE + lane];
+    if (wc) cv_nn = wc[base + OCN_WAVE + lane];
+  }
+  float4 w_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (f_n) w_n = weights[k_n];
   for (i64 p0 = 0; p0 < da; p0 += OCN_WAVE) {
-    const i64 p = p0 + lane;
-    int32_t k = 0;
-    unsigned f = 0;
-    int32_t cv = 1;
-    if (p < da) {
-      k = colA[a0 + p]; f = flags[base + p];
-      if (wc) cv = wc[base + p];
+    const int32_t k = k_n, cv = cv_n;
+    const unsigned f = f_n;
+    const float4 wk = w_n;
+    k_n = k_nn; f_n = f_nn; cv_n = cv_nn;
+    w_n = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f_n) w_n = weights[k_n];
+    k_nn = 0; f_nn = 0; cv_nn = 1;
+    if (p0 + 2 * OCN_WAVE + lane < da) {
+      k_nn = colA[a0 + p0 + 2 * OCN_WAVE + lane]; f_nn = flags[base + p0 + 2 * OCN_WAVE + lane];
+      if (wc) cv_nn = wc[base + p0 + 2 * OCN_WAVE + lane];
     }
     float wa = 0.f, wb = 0.f;
-    if (f) entry_weights(f, weights[k], (float)cv, wa, wb);
-    const unsigned long long m = __ballot((wa != 0.f) | (wb != 0.f));
+    if (f) entry_weights(f, wk, (float)cv, wa, wb);
+    const bool need = (wa != 0.f) | (wb != 0.f);
+    const unsigned long long m = __ballot(need);
     const int n = __popcll(m);
     if (n == 0) continue;
-    // compaction: lane r takes the entry of rank r
-    const int sl = lane < n ? select_bit64(m, lane) : 0;
-    const int32_t kc = __shfl(k, sl, OCN_WAVE);
-    const float wac = __shfl(wa, sl, OCN_WAVE), wbc = __shfl(wb, sl, OCN_WAVE);
-    for (int r0 = 0; r0 < n; r0 += G * UNR) {
-      float4 x[UNR][NV];
+    if (need) {                              // compaction by rank
+      const int rank = __popcll(m & ((1ull << lane) - 1ull));
+      s_k[wv][rank] = k;
+      s_w[wv][rank] = make_float2(wa, wb);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float4 x[UNR][NV];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-        const int r = r0 + u * G + g;
-        const int32_t kk = __shfl(kc, r & 63, OCN_WAVE);
-        if (r < n) {
-          const float4* row = h4 + (i64)kk * rowq + gl;
+    for (int u = 0; u < UNR; ++u) {
+      const int r = u * G + g;
+      const float4* row = h4 + (i64)s_k[wv][r < n ? r : 0] * rowq + gl;
 #pragma unroll
-          for (int v = 0; v < NV; ++v) x[u][v] = row[v * LPE];
-        } else {
+      for (int v = 0; v < NV; ++v) x[u][v] = r < n ? row[v * LPE] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
-          for (int v = 0; v < NV; ++v) x[u][v] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+    for (int u = 0; u < UNR; ++u) {
+      const int r = u * G + g;
+      if (r < n) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) s_x[wv][r][gl + v * LPE] = x[u][v];
       }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (g == 0) {
+      for (int r = 0; r < n; ++r) {
+        const float2 wr = s_w[wv][r];
 #pragma unroll
-      for (int u = 0; u < UNR; ++u) {
-#pragma unroll
-        for (int gg = 0; gg < G; ++gg) {
-          const int r = r0 + u * G + gg;     // wave-uniform
-          if (r < n) {
-            const float war = __shfl(wac, r, OCN_WAVE), wbr = __shfl(wbc, r, OCN_WAVE);
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-              float4 xs;
-              xs.x = __shfl(x[u][v].x, gg * LPE + gl, OCN_WAVE);
-              xs.y = __shfl(x[u][v].y, gg * LPE + gl, OCN_WAVE);
-              xs.z = __shfl(x[u][v].z, gg * LPE + gl, OCN_WAVE);
-              xs.w = __shfl(x[u][v].w, gg * LPE + gl, OCN_WAVE);
-              axpy4(acc1[v], war, xs);
-              axpy4(acc2[v], wbr, xs);
-            }
-          }
+        for (int v = 0; v < NV; ++v) {
+          const float4 xs = s_x[wv][r][gl + v * LPE];
+          axpy4(acc1[v], wr.x, xs);
+          axpy4(acc2[v], wr.y, xs);
         }
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   if (g == 0) pool_store<LPE, NV>(e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
 }
 
-// One workgroup per batch row whose source row is longer than LONG_ROW (hub sources): the 256/LPE
+// One workgroup per batch row whose source row is longer than LONG_ROW (hub sources): the 1024/LPE
 // lane groups pool contiguous segments, partial sums meet in LDS and are added in segment order.
+#define LONG_THREADS 1024     /* few hub rows, each as parallel as a workgroup gets */
 template <int LPE, int NV>
-__global__ __launch_bounds__(OCN_BLOCK) void cn_gather_long_kernel(
+__global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
     const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
     const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
     float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
-  constexpr int NG = OCN_BLOCK / LPE;       // lane groups per workgroup
+  constexpr int NG = LONG_THREADS / LPE;    // lane groups per workgroup
   __shared__ float4 s_part[NG][2][LPE * NV];
   const i64 e = blockIdx.x;
   const i64 i = src[e], j = dst[e];
@@ -817,7 +822,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_long_kernel(
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
   // hub rows are few and long: more gathers in flight per lane group where the registers allow
-  pool_range<LPE, NV, (LPE * NV <= 16 ? 16 : (LPE * NV <= 32 ? 8 : 4))>(pb, pe, a0, off[e], gl, gbase, colA, flags, wc,
+  pool_range<LPE, NV, (LPE * NV <= 32 ? 8 : 4)>(pb, pe, a0, off[e], gl, gbase, colA, flags, wc,
                                                                        weights, h4, rowq, acc1, acc2);
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
@@ -958,6 +963,32 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_scatter_kernel(
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
+template <int LPE, int NV>
+static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
+                          const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
+                          const int32_t* wc, const float* weights, const float* h, int32_t H, int64_t max_row_len,
+                          float* xcn1, float* xcn2, float* xij, hipStream_t st) {
+  const i64 epb = (i64)OCN_WPB * (OCN_WAVE / LPE);
+  bool packed = true;
+  if constexpr (LPE <= 16) {
+    if (B * LPE < 262144) {                  // the packed form would not fill the SIMDs
+      hipLaunchKernelGGL((cn_gather_wave_kernel<LPE, NV>), dim3((unsigned)((B + OCN_WPB - 1) / OCN_WPB)),
+                         dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst,
+                         (const i64*)order, (i64)B, (const i64*)off, flags, wc, (const float4*)weights, h, (int)H,
+                         xcn1, xcn2, xij);
+      packed = false;
+    }
+  }
+  if (packed)
+    hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)), dim3(OCN_BLOCK), 0, st,
+                       (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B,
+                       (const i64*)off, flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij);
+  if (max_row_len > LONG_ROW)
+    hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV>), dim3((unsigned)B), dim3(LONG_THREADS), 0, st,
+                       (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags,
+                       wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij);
+}
+
 extern "C" {
 
 int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* rowptrT1,
@@ -1072,20 +1103,7 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream) 
 #define GATHER_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, (const i64*)off, \
                     flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij
 #define LAUNCH_GATHER(LPE, NV)                                                                      \
-  do {                                                                                              \
-    const i64 epb = (i64)OCN_WPB * (OCN_WAVE / (LPE));                                              \
-    if ((LPE) <= 16 && B * (LPE) < 262144) /* the packed form would not fill the SIMDs */            \
-      hipLaunchKernelGGL((cn_gather_wave_kernel<LPE, NV>), dim3((unsigned)((B + OCN_WPB - 1) / OCN_WPB)), \
-                         dim3(OCN_BLOCK), 0, st, GATHER_ARGS);                                      \
-    else                                                                                            \
-      hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)),        \
-                         dim3(OCN_BLOCK), 0, st, GATHER_ARGS);                                      \
-    if (max_row_len > LONG_ROW)                                                                     \
-      hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV>), dim3((unsigned)B), dim3(OCN_BLOCK), 0,   \
-                         st, (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B,   \
-                         (const i64*)off, flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, \
-                         xij);                                                                      \
-  } while (0)
+  launch_gather<LPE, NV>(rowptrA, colA, src, dst, order, B, off, flags, wc, weights, h, H, max_row_len, xcn1, xcn2, xij, st)
 
 int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
                   const int64_t* dst, const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
