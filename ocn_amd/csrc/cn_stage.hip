@@ -568,9 +568,10 @@ __device__ __forceinline__ void pool_range(i64 p_begin, i64 p_end, i64 a0, i64 b
                                            const int32_t* __restrict__ wc, const float4* __restrict__ weights,
                                            const float4* __restrict__ h4, i64 rowq, float4 (&acc1)[NV],
                                            float4 (&acc2)[NV]) {
-  // Narrow groups (small H) would otherwise pay one dependent load chain (column id -> column weights)
-  // per LPE positions: a lane fetches PT positions per round, so a round always covers 64 of them.
-  constexpr int PT = (OCN_WAVE / LPE) < 8 ? (OCN_WAVE / LPE) : 8;
+  // PT positions per lane and round.  (PT = 64/LPE, so that a round always covers 64 positions, was
+  // measured: it does not help the small-batch case — cn_gather_wave_kernel is what does — and costs the
+  // ddi shape 55 %: B = 32 768, H = 64, dense rows served from L2.)
+  constexpr int PT = 1;
   for (i64 p0 = p_begin; p0 < p_end; p0 += LPE * PT) {
     int32_t k[PT];
     unsigned f[PT];
@@ -794,8 +795,10 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_wave_kernel(
 
 // One workgroup per batch row whose source row is longer than LONG_ROW (hub sources): the 1024/LPE
 // lane groups pool contiguous segments, partial sums meet in LDS and are added in segment order.
-#define LONG_THREADS 1024     /* few hub rows, each as parallel as a workgroup gets */
-template <int LPE, int NV>
+// LONG_THREADS: 1024 for small batches (few hub rows, each as parallel as a workgroup gets), 256 for
+// large ones (one workgroup is launched per batch row and all but the hub rows' leave at once: 32 768
+// x 16 waves of that cost the ddi shape 0.2 ms).
+template <int LPE, int NV, int LONG_THREADS>
 __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
     const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
@@ -983,10 +986,13 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
     hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)), dim3(OCN_BLOCK), 0, st,
                        (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B,
                        (const i64*)off, flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij);
-  if (max_row_len > LONG_ROW)
-    hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV>), dim3((unsigned)B), dim3(LONG_THREADS), 0, st,
-                       (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags,
-                       wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij);
+#define LONG_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, wc, \
+                  (const float4*)weights, h, (int)H, xcn1, xcn2, xij
+  if (max_row_len > LONG_ROW) {
+    if (B <= 4096) hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV, 1024>), dim3((unsigned)B), dim3(1024), 0, st, LONG_ARGS);
+    else hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV, 256>), dim3((unsigned)B), dim3(256), 0, st, LONG_ARGS);
+  }
+#undef LONG_ARGS
 }
 
 extern "C" {
