@@ -34,17 +34,28 @@ def _host_staged(t: Tensor, group) -> bool:
     return t.is_cuda and dist.get_backend(group) == "gloo"
 
 
-def allreduce_hist(hist: Tensor, group=None) -> Tensor:
+def allreduce_hist(hist: Tensor, group=None, valued: bool = True) -> Tensor:
     """In-place sum of the packed per-column histograms (int64 [N, 2]: integer fields, so the sum is
-    exact and order-independent) over the edge shards."""
+    exact and order-independent) over the edge shards.  ``valued=False`` (pattern route: the second
+    word, the walk-count sums, is all zero) moves only the packed word: half the bytes on the wire."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        if _host_staged(hist, group):
-            tmp = hist.cpu()
+        buf = hist if valued else hist[:, 0].contiguous()
+        if _host_staged(buf, group):
+            tmp = buf.cpu()
             dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
-            hist.copy_(tmp)
+            buf.copy_(tmp)
         else:
-            dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        if not valued:
+            hist[:, 0].copy_(buf)
     return hist
+
+
+def check_global_batch(total: int) -> None:
+    """The column counts travel in 21-bit fields (ocn_hip.h): they must hold the GLOBAL batch."""
+    from .ops import MAX_BATCH
+    if total > MAX_BATCH:
+        raise ValueError(f"global candidate batch of {total} edges exceeds the histogram field width ({MAX_BATCH})")
 
 
 def gather_scores(local: Tensor, total: int, group=None) -> Tensor:
@@ -54,8 +65,11 @@ def gather_scores(local: Tensor, total: int, group=None) -> Tensor:
     world = dist.get_world_size(group)
     bounds = shard_bounds(total, world)
     width = max(e - s for s, e in bounds)
-    pad = local.new_zeros((width,) + tuple(local.shape[1:]))
-    pad[: local.shape[0]] = local
+    if local.shape[0] == width and local.is_contiguous():
+        pad = local                              # equal slices (total % world == 0): nothing to pad
+    else:
+        pad = local.new_zeros((width,) + tuple(local.shape[1:]))
+        pad[: local.shape[0]] = local
     if _host_staged(local, group):
         parts = [torch.empty_like(pad, device="cpu") for _ in range(world)]
         dist.all_gather(parts, pad.cpu(), group=group)
@@ -75,6 +89,7 @@ def sharded_predict(predictor, h: Tensor, adj, adj2, edges: Tensor, args=None, g
     from .utils import adjoverlap
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    check_global_batch(edges.shape[1])
     s, e = shard_bounds(edges.shape[1], world)[rank]
     mine = edges[:, s:e].contiguous()
     predictor.set_edge_sharding(group if world > 1 else None, enabled=world > 1)

@@ -437,7 +437,7 @@ class _CNPredictorBase(nn.Module):
     def _exchange(self, st):
         if self._sharded:
             from .dist import allreduce_hist
-            allreduce_hist(st.hist, self._shard_group)
+            allreduce_hist(st.hist, self._shard_group, valued=st.walk)
             ops._mark("allreduce_hist")
         return st
 

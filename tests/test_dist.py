@@ -48,6 +48,15 @@ def _worker(rank, world, port, B, out):
         local = _hist_of(O, adj, adj2, edges[:, s:e], n)
         glob = allreduce_hist(local.clone())
         ok_hist = torch.equal(glob, _hist_of(O, adj, adj2, edges, n))
+        # the packed layout of the product (int64 [N, 2]); pattern route: only word 0 travels
+        pk = torch.stack([local[:, 0].long() | (local[:, 1].long() << 21) | (local[:, 2].long() << 42),
+                          torch.full((n,), 7 + rank, dtype=torch.int64)], dim=1)
+        want = _hist_of(O, adj, adj2, edges, n).long()
+        got = allreduce_hist(pk.clone(), valued=False)
+        ok_hist &= torch.equal(got[:, 0], want[:, 0] | (want[:, 1] << 21) | (want[:, 2] << 42))
+        ok_hist &= bool((got[:, 1] == 7 + rank).all())                # untouched
+        got = allreduce_hist(pk.clone(), valued=True)
+        ok_hist &= bool((got[:, 1] == 7 * world + sum(range(world))).all())
         # scores: any per-edge function of the global edge id; gather must restore batch order
         mine = (torch.arange(s, e, dtype=torch.float32) * 0.5 + 1).reshape(-1, 1)
         allsc = gather_scores(mine, B)
