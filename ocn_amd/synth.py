@@ -111,3 +111,60 @@ def sample_edges(row: Tensor, col: Tensor, n: int, B: int, seed: int = 1, pos_fr
     neg = torch.randint(0, n, (2, B - n_pos), generator=g)
     e = torch.cat([pos.to(torch.long), neg], dim=1)
     return e[:, torch.randperm(B, generator=g)].contiguous()
+
+
+def loaddataset_like(name: str, use_valedges_as_input: bool = False, seed: int = 0, scale: float = 1.0,
+                     val_ratio: float = 0.05, test_ratio: float = 0.10, n_neg: int = 0, feat: int = 0):
+    """(data, split_edge) with the fields the reference drivers read from ``ogbdataset.loaddataset``
+    (/root/reference/ogbdataset.py:29-71), on a seeded synthetic graph of the named shape:
+
+    ``data.x`` (features, or node ids with ``data.max_x`` for ppa / ddi as in :47-52), ``data.adj_t``
+    (symmetric adjacency of the TRAINING edges), ``data.full_adj_t`` (+ validation edges when
+    ``use_valedges_as_input``, :61-68), ``data.num_nodes``; ``split_edge[train|valid|test]['edge']``
+    [m, 2] (each undirected edge once) and ``['edge_neg']`` [n_neg, 2] uniform random non-self pairs.
+    citation2's per-positive negatives (``target_node_neg``) are given as ``['edge_neg']`` of shape
+    [m, n_neg_per, 2] when ``name == 'citation2'``."""
+    from types import SimpleNamespace
+    from .sparse import SparseTensor
+    ei, n, shape = dataset_like(name, seed=seed, scale=scale)
+    g = torch.Generator().manual_seed(seed + 17)
+    m = ei.shape[1]
+    perm = torch.randperm(m, generator=g)
+    n_val, n_test = int(m * val_ratio), int(m * test_ratio)
+    idx = {"valid": perm[:n_val], "test": perm[n_val:n_val + n_test], "train": perm[n_val + n_test:]}
+    split_edge = {k: {"edge": ei[:, v].t().contiguous()} for k, v in idx.items()}
+    n_neg = n_neg or max(n_val, 1)
+
+    def negatives(shape_):
+        a = torch.randint(0, n, shape_, generator=g)
+        b = torch.randint(0, n - 1, shape_, generator=g)
+        return torch.stack([a, b + (b >= a).long()], dim=-1)          # no self pairs
+
+    if name == "citation2":
+        for k in ("valid", "test"):
+            src = split_edge[k]["edge"][:, 0]
+            per = max(n_neg // max(src.numel(), 1), 1) if n_neg else 1000
+            tgt = torch.randint(0, n, (src.numel(), per), generator=g)
+            split_edge[k]["edge_neg"] = torch.stack([src[:, None].expand_as(tgt), tgt], dim=-1)
+    else:
+        for k in ("valid", "test"):
+            split_edge[k]["edge_neg"] = negatives((n_neg,))
+    data = SimpleNamespace(num_nodes=n, max_x=-1, edge_weight=None)
+    train_ei = split_edge["train"]["edge"].t()
+    data.edge_index = torch.cat([train_ei, train_ei.flip(0)], dim=1)
+    data.adj_t = SparseTensor.from_edge_index(data.edge_index, sparse_sizes=(n, n)).to_symmetric().coalesce()
+    gx = torch.Generator().manual_seed(seed + 29)
+    if name == "ppa":
+        data.x = torch.randint(0, shape["feat"], (n,), generator=gx)
+        data.max_x = int(data.x.max())
+    elif name == "ddi":
+        data.x = torch.arange(n)
+        data.max_x = n
+    else:
+        data.x = torch.randn(n, feat or shape["feat"], generator=gx)
+    if use_valedges_as_input:
+        full = torch.cat([data.edge_index, split_edge["valid"]["edge"].t()], dim=1)
+        data.full_adj_t = SparseTensor.from_edge_index(full, sparse_sizes=(n, n)).coalesce().to_symmetric()
+    else:
+        data.full_adj_t = data.adj_t
+    return data, split_edge

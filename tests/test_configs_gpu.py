@@ -166,3 +166,20 @@ def test_train_loop_like_the_reference_driver(hiplib):
         losses.append(sum(tot) / len(tot))
     assert losses[-1] < losses[0] - 0.05, losses
     assert predictor.innerprod.item() != 0.0 and predictor.n > 0
+
+
+def test_example_driver_trains_and_scores(hiplib):
+    """examples/run_like_reference.py: the reference's epoch loop (train -> test -> Hits@K) end to end on a
+    Cora-shaped synthetic dataset, with --maskinput and --use_valedges_as_input as README.md:27 runs it."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "run_like_reference.py")
+    spec = importlib.util.spec_from_file_location("run_like_reference", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(["--dataset", "cora", "--epochs", "4", "--maskinput", "--use_valedges_as_input", "--hiddim", "64",
+                    "--feat", "64", "--batch_size", "1152"])
+    losses = [o[0] for o in out]
+    assert all(l == l for l in losses) and losses[-1] < losses[0]
+    hits = out[-1][1]["Hits@100"]
+    assert all(0.0 <= v <= 1.0 for v in hits) and hits[0] > 0.0
