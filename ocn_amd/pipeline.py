@@ -88,3 +88,31 @@ def score_edges(predictor, h: Tensor, adj, adj2, edges: Tensor, batch_size: int,
         done.append(scorer.mlp_stream.record_event())
     scorer.end(outs)
     return torch.cat(outs, dim=0).squeeze(-1) if outs else h.new_zeros(0)
+
+
+@torch.no_grad()
+def score_mrr_split(predictor, h: Tensor, adj, source: Tensor, target: Tensor, target_neg: Tensor,
+                    batch_size: int, args=None, evaluator=None):
+    """``test_split`` of the citation2 driver (NeighborOverlapCitation2.py:227-254): positives
+    (source, target) and, per positive, ``target_neg.shape[1]`` negatives sharing its source, each
+    scored through ``get_cn1_cn2`` in ``PermIterator(.., training=False)`` batches — same batch
+    composition as the reference, scores kept on the device.  Returns (pos_pred [n], neg_pred [n, n_neg])
+    or, with an ``evaluator``, the mean of its ``mrr_list``."""
+    from .utils import get_cn1_cn2
+    if predictor.training:
+        raise RuntimeError("score_mrr_split is the eval path; call predictor.eval() first")
+
+    def run(src_all: Tensor, dst_all: Tensor) -> Tensor:
+        outs = []
+        for perm in PermIterator(src_all.device, src_all.shape[0], batch_size, training=False):
+            e = torch.stack((src_all[perm], dst_all[perm]))
+            cn1, cn2 = get_cn1_cn2(adj, e)
+            outs.append(predictor(h, adj, cn1, cn2, e, args).reshape(-1))
+        return torch.cat(outs, dim=0) if outs else h.new_zeros(0)
+
+    pos_pred = run(source, target)
+    n_neg = target_neg.shape[1]
+    neg_pred = run(source.view(-1, 1).repeat(1, n_neg).view(-1), target_neg.reshape(-1)).view(-1, n_neg)
+    if evaluator is None:
+        return pos_pred, neg_pred
+    return evaluator.eval({"y_pred_pos": pos_pred, "y_pred_neg": neg_pred})["mrr_list"].mean().item()

@@ -183,3 +183,40 @@ def test_example_driver_trains_and_scores(hiplib):
     assert all(l == l for l in losses) and losses[-1] < losses[0]
     hits = out[-1][1]["Hits@100"]
     assert all(0.0 <= v <= 1.0 for v in hits) and hits[0] > 0.0
+
+
+def test_citation2_mrr_layout_matches_the_oracle_loop(hiplib):
+    """pipeline.score_mrr_split == the citation2 driver's test_split (NeighborOverlapCitation2.py:227-254)
+    restated with the oracle: per positive n_neg negatives sharing the source, walk-count route, cn7, MRR
+    from the OGB rank definition."""
+    import ocn_amd.model as M
+    from ocn_amd.evaluate import Evaluator
+    from ocn_amd.pipeline import score_mrr_split
+    n, shape, oadj, adj = _graph("citation2", 0.001)
+    H, n_pos, n_neg, bs = 32, 60, 25, 512
+    torch.manual_seed(4)
+    h = torch.randn(n, H)
+    pred = M.predictor_dict["cn7"](H, H, 1, 3, 0.0, 0.0, True, use_xlin=True, tailact=True).eval()
+    sd = _sd(pred)
+    args = SimpleNamespace(sum=1.0)
+    g = torch.Generator().manual_seed(8)
+    pick = torch.randperm(oadj.nnz, generator=g)[:n_pos]
+    source, target = oadj.row[pick], oadj.col[pick]
+    target_neg = torch.randint(0, n, (n_pos, n_neg), generator=g)
+
+    def oracle_run(src, dst):
+        outs = []
+        for s0 in range(0, src.numel(), bs):                      # PermIterator(.., False): contiguous slices, ragged tail kept
+            e = torch.stack((src[s0:s0 + bs], dst[s0:s0 + bs]))
+            c1, c2 = O.get_cn1_cn2(oadj, e)
+            outs.append(O.cn7_forward(sd, h, c1, c2, e, args.sum, True, True).reshape(-1))
+        return torch.cat(outs)
+
+    ref_pos = oracle_run(source, target)
+    ref_neg = oracle_run(source.view(-1, 1).repeat(1, n_neg).view(-1), target_neg.reshape(-1)).view(-1, n_neg)
+    pos, neg = score_mrr_split(pred.to(DEV), h.to(DEV), adj, source.to(DEV), target.to(DEV), target_neg.to(DEV), bs, args)
+    assert close(pos, ref_pos) and close(neg, ref_neg)
+    ev = Evaluator("ogbl-citation2")
+    want = ev.eval({"y_pred_pos": ref_pos, "y_pred_neg": ref_neg})["mrr_list"].mean().item()
+    got = score_mrr_split(pred, h.to(DEV), adj, source.to(DEV), target.to(DEV), target_neg.to(DEV), bs, args, evaluator=ev)
+    assert got == pytest.approx(want, abs=1e-6)
