@@ -141,6 +141,21 @@ int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA,
                   const float* weights /* [N][4] */, const float* h, int32_t H, int64_t max_row_len,
                   float* xcn1, float* xcn2, float* xij, void* stream);
 
+/* The 3-hop predictor cn6 (model.py:2535-2951), pattern route.  Two intersection passes over the same
+ * candidate batch — (A, A, A²) into flagsA / histA and (A, A³) into flagsB / histB (bit 0 = cn3 entry,
+ * n1 field = cn3 column count) — then:
+ *   ocn_cn_weights_cn6: histA -> {inv1, t, inv2, 0} exactly as cn5 (:2546-2714), histB -> {1/S3,0,0,0}
+ *     with S3 the column sums of cn3 - nip*ncn1 - nip*ncn2' over the union pattern (:2846-2931; in
+ *     eval all three inner products are the stored buffer), nip_out[0] = nip;
+ *   ocn_cn_gather3: xcn1, xcn2, xcn3 = spmm_add of the three normalised matrices (:2712-2713, :2933),
+ *     xij = x_i * x_j.  H in {16, 32, 64, 128, 256, 512}. */
+int ocn_cn_weights_cn6(uint64_t* histA, uint64_t* histB, int64_t N, const float* innerprod, int32_t* scalars,
+                       float* nip_out, void* stream);
+int ocn_cn_gather3(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
+                   const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flagsA,
+                   const uint8_t* flagsB, const float* weightsA, const float* weightsB, const float* nip,
+                   const float* h, int32_t H, float* xcn1, float* xcn2, float* xcn3, float* xij, void* stream);
+
 /* Backward of the pooling with respect to h (training drop-in): for upstream
  * gradients g1, g2, g3 of xcn1, xcn2, xij ([B][H] each),
  *   dh[k] += w1[k] g1[e] + w2(e,k) g2[e]  over the CN entries (the transposed spmm_add),

@@ -536,6 +536,47 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn5_column_weights(u64* __restrict_
   }
 }
 
+// cn6 (model.py:2535-2951), pattern route: stage 1 is cn5's (histA = {n1, n2, n_union} of cn1 / cn2,
+// rewritten in place as {inv1, t, inv2, 0}); stage 2 orthogonalises cn3 (histB: its n1 field counts the
+// cn3 entries of the column) against both normalised matrices,
+//   v3 = [in cn3] - nip*inv1*[in cn1] - nip*ncn2,     S3 = column sum of v3 (0 -> 1),
+// and histB is rewritten as {1/S3, 0, 0, 0}.  The column sums are formed from the integer counts in
+// fp64 (exact for nip == 0: S2 = n2, S3 = n3), as for cn5.  nip_out[0] receives nip for the gather.
+__global__ __launch_bounds__(OCN_BLOCK) void cn6_column_weights(u64* __restrict__ histA, u64* __restrict__ histB,
+                                                                i64 N, const float* __restrict__ innerprod,
+                                                                const int32_t* __restrict__ scalars,
+                                                                float* __restrict__ nip_out) {
+  const int sc = scalars[0];
+  float scale;
+  if (sc == 0) scale = 1.0f;
+  else if (sc == -1) scale = 0.0f;
+  else scale = 1.0f / (float)(sc + 0x7fffffff + 1);
+  const float ip = innerprod[0];
+  const float nip = scale > 0.0f ? ip / scale : ip;
+  if (blockIdx.x == 0 && threadIdx.x == 0) nip_out[0] = nip;
+  float4* wa = reinterpret_cast<float4*>(histA);
+  float4* wb = reinterpret_cast<float4*>(histB);
+  for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (i64)gridDim.x * blockDim.x) {
+    const u64 pa = histA[2 * c], pb = histB[2 * c];
+    if (pa == 0 && pb == 0) continue;
+    const int n1 = hf_n1(pa), n2 = hf_n2(pa), nb = n1 + n2 - hf_nu(pa), n3 = hf_n1(pb);
+    const float inv1 = n1 >= 2 ? 1.0f / (float)n1 : 0.0f;
+    const float t = __fmul_rn(nip, inv1);
+    const float v_both = __fsub_rn(1.0f, t), v_only2 = __fsub_rn(1.0f, __fmul_rn(nip, 0.0f)), v_only1 = __fsub_rn(0.0f, t);
+    float S2 = (float)((double)(n2 - nb) * (double)v_only2 + (double)nb * (double)v_both +
+                       (double)(n1 - nb) * (double)v_only1);
+    if (S2 == 0.0f) S2 = 1.0f;
+    const float inv2 = 1.0f / S2;
+    // column sum of the normalised cn2' values (1 up to rounding, or 0)
+    const double s2n = (double)(n2 - nb) * (double)__fmul_rn(v_only2, inv2) + (double)nb * (double)__fmul_rn(v_both, inv2) +
+                       (double)(n1 - nb) * (double)__fmul_rn(v_only1, inv2);
+    float S3 = (float)((double)n3 - (double)n1 * (double)t - (double)nip * s2n);
+    if (S3 == 0.0f) S3 = 1.0f;
+    wa[c] = make_float4(inv1, t, inv2, 0.0f);
+    wb[c] = make_float4(1.0f / S3, 0.0f, 0.0f, 0.0f);
+  }
+}
+
 __global__ __launch_bounds__(OCN_BLOCK) void cn7_column_weights(u64* __restrict__ hist, i64 N,
                                                                 float sum_fill) {
   float4* wout = reinterpret_cast<float4*>(hist);
@@ -849,6 +890,94 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
   }
 }
 
+// cn6 pooling: three pooled vectors.  flagsA carries the cn1 / cn2 bits, flagsB's bit 0 the cn3 bit (two
+// intersection passes over the same source rows, so the same `off`); per entry
+//   w1 = [cn1]*inv1,  w2 = ([cn2] - t*[cn1])*inv2,  w3 = (([cn3] - t*[cn1]) - nip*w2)*inv3,
+// each product / difference rounded separately, pooled in ascending column order.  LPE lanes per
+// batch row, like cn_gather_kernel (no hub-row split: every row keeps the sequential order).
+template <int LPE, int NV>
+__global__ __launch_bounds__(OCN_BLOCK) void cn_gather3_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
+    const i64* __restrict__ off, const uint8_t* __restrict__ flagsA, const uint8_t* __restrict__ flagsB,
+    const float4* __restrict__ wA, const float4* __restrict__ wB, const float* __restrict__ nip_p,
+    const float* __restrict__ h, int H, float* __restrict__ xcn1, float* __restrict__ xcn2,
+    float* __restrict__ xcn3, float* __restrict__ xij) {
+  constexpr int GPW = OCN_WAVE / LPE;
+  constexpr int UNR = 4;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane % LPE;
+  const int gbase = lane - gl;
+  const i64 slot = ((i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
+  if (slot >= B) return;
+  const i64 e = order ? order[slot] : slot;
+  const i64 i = src[e], j = dst[e];
+  const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+  const i64 base = off[e];
+  const float nip = nip_p[0];
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  const i64 rowq = H >> 2;
+  float4 acc1[NV], acc2[NV], acc3[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = acc3[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (i64 p0 = 0; p0 < da; p0 += LPE) {
+    const i64 p = p0 + gl;
+    int32_t k = 0;
+    unsigned fa = 0, fb = 0;
+    if (p < da) { k = colA[a0 + p]; fa = flagsA[base + p]; fb = flagsB[base + p] & OCN_F_CN1; }
+    float w1 = 0.f, w2 = 0.f, w3 = 0.f;
+    if (fa | fb) {
+      const float4 a = wA[k];
+      const float inv3 = wB[k].x;
+      const float tt = (fa & OCN_F_CN1) ? a.y : 0.f;
+      w1 = (fa & OCN_F_CN1) ? a.x : 0.f;
+      w2 = __fmul_rn(__fsub_rn((fa & OCN_F_CN2) ? 1.0f : 0.f, tt), a.z);
+      w3 = __fmul_rn(__fsub_rn(__fsub_rn(fb ? 1.0f : 0.f, tt), __fmul_rn(nip, w2)), inv3);
+    }
+    const bool need = (w1 != 0.f) | (w2 != 0.f) | (w3 != 0.f);
+    unsigned long long m = __ballot(need);
+    if (LPE < 64) m = (m >> gbase) & ((1ull << (LPE & 63)) - 1ull);
+    while (m) {
+      int bsel[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        bsel[u] = m ? (__ffsll((long long)m) - 1) : -1;
+        m &= m - 1;
+      }
+      float ww1[UNR], ww2[UNR], ww3[UNR];
+      float4 x[UNR][NV];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int sl = gbase + (bsel[u] < 0 ? 0 : bsel[u]);
+        const int32_t kk = __shfl(k, sl, OCN_WAVE);
+        ww1[u] = __shfl(w1, sl, OCN_WAVE);
+        ww2[u] = __shfl(w2, sl, OCN_WAVE);
+        ww3[u] = __shfl(w3, sl, OCN_WAVE);
+        if (bsel[u] >= 0) {
+          const float4* row = h4 + (i64)kk * rowq + gl;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) x[u][v] = row[v * LPE];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (bsel[u] >= 0) {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            axpy4(acc1[v], ww1[u], x[u][v]);
+            axpy4(acc2[v], ww2[u], x[u][v]);
+            axpy4(acc3[v], ww3[u], x[u][v]);
+          }
+        }
+      }
+    }
+  }
+  pool_store<LPE, NV>(e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
+  float4* o3 = reinterpret_cast<float4*>(xcn3) + e * rowq + gl;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) o3[v * LPE] = acc3[v];
+}
+
 // any H: one wave per edge, one feature per lane per 64-wide chunk (re-walks the flags per chunk)
 __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_generic(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
@@ -1097,6 +1226,19 @@ int ocn_cn_weights_cn5(uint64_t* hist, int64_t N, const float* innerprod, int32_
   return launch_status();
 }
 
+int ocn_cn_weights_cn6(uint64_t* histA, uint64_t* histB, int64_t N, const float* innerprod, int32_t* scalars,
+                       float* nip_out, void* stream) {
+  if (N < 0 || (N > 0 && (!histA || !histB || !innerprod || !scalars || !nip_out))) return OCN_EINVAL;
+  if (N == 0) return 0;
+  const int grid = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cn5_column_stats, dim3(grid < 512 ? grid : 512), dim3(OCN_BLOCK), 0, st,
+                     (const u64*)histA, (i64)N, scalars);
+  hipLaunchKernelGGL(cn6_column_weights, dim3(grid), dim3(OCN_BLOCK), 0, st, (u64*)histA, (u64*)histB, (i64)N,
+                     innerprod, (const int32_t*)scalars, nip_out);
+  return launch_status();
+}
+
 int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream) {
   if (N < 0 || (N > 0 && !hist)) return OCN_EINVAL;
   if (N == 0) return 0;
@@ -1129,6 +1271,33 @@ int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* sr
     default:   /* generic widths: every row by one wave, no long-row split */
       hipLaunchKernelGGL(cn_gather_generic, dim3((unsigned)((B + OCN_WPB - 1) / OCN_WPB)),
                          dim3(OCN_BLOCK), 0, st, GATHER_ARGS);
+  }
+  return launch_status();
+}
+
+#define LAUNCH_GATHER3(LPE, NV)                                                                      \
+  hipLaunchKernelGGL((cn_gather3_kernel<LPE, NV>),                                                   \
+                     dim3((unsigned)((B + (i64)OCN_WPB * (OCN_WAVE / (LPE)) - 1) / ((i64)OCN_WPB * (OCN_WAVE / (LPE))))), \
+                     dim3(OCN_BLOCK), 0, (hipStream_t)stream, (const i64*)rowptrA, colA, (const i64*)src,      \
+                     (const i64*)dst, (const i64*)order, (i64)B, (const i64*)off, flagsA, flagsB,             \
+                     (const float4*)weightsA, (const float4*)weightsB, nip, h, (int)H, xcn1, xcn2, xcn3, xij)
+
+int ocn_cn_gather3(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
+                   const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flagsA,
+                   const uint8_t* flagsB, const float* weightsA, const float* weightsB, const float* nip,
+                   const float* h, int32_t H, float* xcn1, float* xcn2, float* xcn3, float* xij, void* stream) {
+  if (B < 0 || H <= 0) return OCN_EINVAL;
+  if (B == 0) return 0;
+  if (!rowptrA || !src || !dst || !off || !weightsA || !weightsB || !nip || !h || !xcn1 || !xcn2 || !xcn3 || !xij)
+    return OCN_EINVAL;
+  switch (H) {
+    case 16:  LAUNCH_GATHER3(4, 1); break;
+    case 32:  LAUNCH_GATHER3(8, 1); break;
+    case 64:  LAUNCH_GATHER3(16, 1); break;
+    case 128: LAUNCH_GATHER3(32, 1); break;
+    case 256: LAUNCH_GATHER3(64, 1); break;
+    case 512: LAUNCH_GATHER3(64, 2); break;
+    default: return OCN_EINVAL;
   }
   return launch_status();
 }

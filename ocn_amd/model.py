@@ -583,7 +583,49 @@ class CNLinkPredictorbaselearn(_CNPredictorBase):
         return self.multidomainforward(x, adj, cn1, cn2, tar_ei, filled1, [])
 
 
+class CNLinkPredictor3hopCNs(_CNPredictorBase):
+    """cn6 (model.py:2445-2951): the 3-hop predictor.  cn1 / cn2 as cn5; cn3 = N(i) ∩ N³(j) is
+    orthogonalised against BOTH normalised matrices and column-normalised; a fourth head ``xcn3lin`` and
+    ``alpha[2]`` join the mix.  ``forward(x, adj, cn1, cn2, cn3, tar_ei, args)`` as in the reference
+    (:2950); no reference driver builds a cn3 — ``adjoverlap(adj, adj3, e)`` with adj3 the pattern of
+    A·A·A is its natural source.  Forward only (eval / no-grad): the reference's training path updates the
+    one ``innerprod`` buffer three times per call with three different quantities (:2527-2533) and is
+    reached by no driver."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout, edrop=0.0,
+                 ln=False, cndeg=-1, use_xlin=False, tailact=False, twolayerlin=False, beta=1.0):
+        super().__init__(in_channels, hidden_channels, out_channels, num_layers, dropout, edrop, ln, cndeg,
+                         use_xlin, tailact, twolayerlin, beta)
+        H, p = hidden_channels, dropout
+        norm = nn.LayerNorm(H) if ln else nn.Identity()
+        del self.xcn4lin                                        # cn6 has xcn3lin in its place (:2496-2501)
+        self.xcn3lin = nn.Sequential(nn.Linear(in_channels, H), nn.Dropout(p, inplace=True), nn.ReLU(inplace=True),
+                                     nn.Linear(H, H), norm, nn.Dropout(p, inplace=True), nn.ReLU(inplace=True),
+                                     nn.Linear(H, H))
+
+    def multidomainforward(self, x, adj, cn1, cn2, cn3, tar_ei, args=None, cndropprobs: Iterable[float] = []):
+        from .utils import fuse3
+        if self.training or (torch.is_grad_enabled() and x.requires_grad):
+            raise NotImplementedError("cn6 is forward-only here: call .eval() and score under torch.no_grad()")
+        st = fuse3(cn1, cn2, cn3, tar_ei)
+        if self._sharded:
+            from .dist import allreduce_hist
+            allreduce_hist(st.a.hist, self._shard_group, valued=False)
+            allreduce_hist(st.b.hist, self._shard_group, valued=False)
+        wa, wb, nip = st.weights(self.innerprod)
+        xcn1, xcn2, xcn3, xij = st.gather(wa, wb, nip, x.contiguous())
+        with torch.no_grad():
+            alpha = torch.sigmoid(self.alpha).cumprod(-1)
+            z = (alpha[0] * _seq_eval(self.xcn1lin, xcn1) + alpha[1] * _seq_eval(self.xcn2lin, xcn2)
+                 + alpha[2] * _seq_eval(self.xcn3lin, xcn3) + self.beta * _seq_eval(self.xijlin, xij))
+            return _seq_eval(self.lin, z)
+
+    def forward(self, x, adj, cn1, cn2, cn3, tar_ei, args=None):
+        return self.multidomainforward(x, adj, cn1, cn2, cn3, tar_ei, args)
+
+
 predictor_dict = {
     "cn5": CNLinkPredictorOringin,
+    "cn6": CNLinkPredictor3hopCNs,
     "cn7": CNLinkPredictorbaselearn,
 }

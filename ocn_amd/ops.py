@@ -221,6 +221,39 @@ def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights
     return out[0], out[1], out[2]
 
 
+def cn_weights_cn6(histA: Tensor, histB: Tensor, innerprod: Tensor):
+    """In place: histA -> float32 [N,4] {inv1, t, inv2, 0}, histB -> {1/S3, 0, 0, 0}; returns them and the
+    device scalar nip (ocn_hip.h: ocn_cn_weights_cn6)."""
+    _req(histA, torch.int64, "histA", 2); _req(histB, torch.int64, "histB", 2)
+    if histA.shape != histB.shape:
+        raise ValueError("histA / histB shape mismatch")
+    ip = _req(innerprod.detach().reshape(1).to(torch.float32), torch.float32, "innerprod", 1)
+    scal = torch.zeros(4, dtype=torch.int32, device=histA.device)
+    nip = torch.empty(1, dtype=torch.float32, device=histA.device)
+    check(_lib.lib().ocn_cn_weights_cn6(ptr(histA), ptr(histB), histA.shape[0], ptr(ip), ptr(scal), ptr(nip),
+                                        stream_ptr()), "ocn_cn_weights_cn6")
+    _mark("cn_weights")
+    return histA.view(torch.float32).view(-1, 4), histB.view(torch.float32).view(-1, 4), nip
+
+
+def cn_gather3(rowptrA, colA, src, dst, off, flagsA, flagsB, wA: Tensor, wB: Tensor, nip: Tensor, h: Tensor,
+               order: Optional[Tensor] = None):
+    """(xcn1, xcn2, xcn3, x_i * x_j) of the 3-hop predictor."""
+    _req(wA, torch.float32, "weightsA", 2); _req(wB, torch.float32, "weightsB", 2)
+    _req(h, torch.float32, "h", 2)
+    if wA.shape != (h.shape[0], 4) or wB.shape != (h.shape[0], 4):
+        raise ValueError("weights must be [N,4] with N = h.shape[0]")
+    B, H = src.numel(), h.shape[1]
+    if H not in LN_WIDTHS:
+        raise NotImplementedError(f"cn6 pooling supports hidden widths {LN_WIDTHS}, got {H}")
+    out = torch.empty(4, B, H, dtype=torch.float32, device=h.device)
+    check(_lib.lib().ocn_cn_gather3(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flagsA),
+                                    ptr(flagsB), ptr(wA), ptr(wB), ptr(nip), ptr(h), H, ptr(out[0]), ptr(out[1]),
+                                    ptr(out[2]), ptr(out[3]), stream_ptr()), "ocn_cn_gather3")
+    _mark("cn_gather")
+    return out[0], out[1], out[2], out[3]
+
+
 def cn_gather_backward(rowptrA, colA, src, dst, off, flags, wc, weights: Tensor, h: Tensor, g1: Tensor, g2: Tensor,
                        g3: Tensor, order: Optional[Tensor] = None) -> Tensor:
     """Gradient of (xcn1, xcn2, xij) with respect to h."""

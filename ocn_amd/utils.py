@@ -171,6 +171,42 @@ class CNBatch:
         return self._single().materialize(2 if self.mode == "walk2" else 1)
 
 
+class CNState3:
+    """The 3-hop predictor's batch state: two intersection passes over the same candidates — (A, A, A²) and
+    (A, A³) — sharing the row offsets (both walk the source rows of A)."""
+
+    def __init__(self, adj: SparseTensor, adj2: SparseTensor, adj3: SparseTensor, tarei: Tensor):
+        self.a = CNState(adj, adj, adj2, tarei)
+        self.b = CNState(adj, adj3, None, tarei)
+        self.adj, self.B, self.N = adj, self.a.B, self.a.N
+
+    @property
+    def cnt3(self) -> Tensor:
+        return self.b.cnt1
+
+    def weights(self, innerprod: Tensor):
+        assert self.a._hist_live and self.b._hist_live, "histograms already consumed"
+        self.a._hist_live = self.b._hist_live = False
+        return ops.cn_weights_cn6(self.a.hist, self.b.hist, innerprod)
+
+    def gather(self, wa: Tensor, wb: Tensor, nip: Tensor, h: Tensor):
+        return ops.cn_gather3(self.adj._rowptr, self.adj._col, self.a.src, self.a.dst, self.a.off, self.a.flags,
+                              self.b.flags, wa, wb, nip, h, order=self.a.order)
+
+
+def fuse3(cn1: "CNBatch", cn2: "CNBatch", cn3: "CNBatch", tar_ei: Tensor) -> CNState3:
+    """(cn1, cn2, cn3) = adjoverlap(adj, adj | adj2 | adj3, e) of one candidate batch."""
+    for c in (cn1, cn2, cn3):
+        if not isinstance(c, CNBatch) or c.mode != "pattern":
+            raise NotImplementedError("cn6 takes the handles returned by ocn_amd.utils.adjoverlap")
+    if not (cn1.adj1 is cn2.adj1 is cn3.adj1) or cn1.adj2 is not cn1.adj1:
+        raise NotImplementedError("cn1/cn2/cn3 must come from adjoverlap(adj, adj|adj2|adj3, e) of one adjacency")
+    if ops.validate_indices and not (torch.equal(cn1.tarei, cn2.tarei) and torch.equal(cn1.tarei, cn3.tarei)
+                                     and torch.equal(cn1.tarei, tar_ei)):
+        raise NotImplementedError("cn1, cn2, cn3 and tar_ei must be built from the same candidate edges")
+    return CNState3(cn1.adj1, cn2.adj2, cn3.adj2, cn1.tarei)
+
+
 def fuse(cn1: CNBatch, cn2: CNBatch, tar_ei: Tensor, ws: Optional[dict] = None) -> CNState:
     """One intersection pass for the (cn1, cn2) pair every driver builds from the same candidate
     edges (NeighborOverlap_large.py:76-82,121-159; NeighborOverlap_large_ppa.py:98-133)."""

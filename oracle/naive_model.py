@@ -85,3 +85,35 @@ def cn7_pool(n: int, h: np.ndarray, cn1, cn2_vals, sum_fill: float):
     xcn2 = np.stack([sum((val * h[k] for k, val in r.items()), np.zeros(h.shape[1]))
                      for r in cn2_vals])
     return xcn1, xcn2, dict(S1=S1, inv1=inv1)
+
+
+def three_hop(nb: List[Set[int]], nb2: List[Set[int]]) -> List[Set[int]]:
+    """Row pattern of A²·A: k ∈ N³(j) iff ∃m ∈ N²(j): k ∈ N(m)."""
+    return [set().union(*[nb[m] for m in nb2[j]]) if nb2[j] else set() for j in range(len(nb))]
+
+
+def cn6_pool(n: int, h: np.ndarray, cn1, cn2, cn3, innerprod: float):
+    """3-hop predictor pooling: stage 1 as cn5; stage 2: cn3' = cn3 − nip·ncn1 − nip·ncn2' on the union
+    of the three patterns (ncn2' lives on cn1 ∪ cn2), column-normalised (zero sums -> 1)."""
+    xcn1, xcn2, aux = cn5_pool(n, h, cn1, cn2, innerprod)
+    h = h.astype(np.float64)
+    inv1, S2, v2, nip = aux["inv1"], aux["S2"], aux["v"], aux["nip"]
+    any1 = any(len(r) for r in cn1)
+    nonempty = any1 or any(len(r) for r in cn2) or any(len(r) for r in cn3)
+    present = [inv1[k] for row in cn1 for k in row]
+    scale = (max(present) if present else 0.0) if nonempty else 1.0
+    nip_b = innerprod / scale if scale > 0 else innerprod
+    v3: List[Dict[int, float]] = []
+    for r1, r2v, r3 in zip(cn1, v2, cn3):
+        row = {}
+        for k in sorted(set(r1) | set(r2v) | set(r3)):
+            row[k] = ((1.0 if k in r3 else 0.0) - nip_b * (inv1[k] if k in r1 else 0.0)
+                      - nip_b * (r2v[k] / S2[k] if k in r2v else 0.0))
+        v3.append(row)
+    S3 = np.zeros(n)
+    for row in v3:
+        for k, val in row.items():
+            S3[k] += val
+    S3 = np.where(S3 == 0, 1.0, S3)
+    xcn3 = np.stack([sum((val / S3[k] * h[k] for k, val in r.items()), np.zeros(h.shape[1])) for r in v3])
+    return xcn1, xcn2, xcn3, dict(aux, S3=S3, nip=nip)

@@ -318,6 +318,67 @@ def cn5_forward(sd: Dict[str, Tensor], x: Tensor, cn1: SpM, cn2: SpM, tar_ei: Te
 
 
 # ----------------------------------------------------------------------------
+# cn6 = CNLinkPredictor3hopCNs.multidomainforward, eval mode (model.py:2535-2951)
+# ----------------------------------------------------------------------------
+def adj3_sparse(adj: SpM, adj2: SpM) -> SpM:
+    """Pattern of A·A·A = A² · A (values discarded), the 3-hop analogue of NeighborOverlap_large.py:
+    68-74.  No reference driver builds it (cn6 is registered in predictor_dict, model.py:3725, but no
+    driver passes a cn3); cn3 = adjoverlap(adj, adj3, e) is the natural continuation of the cn1 / cn2
+    pair and what ``forward(x, adj, cn1, cn2, cn3, tar_ei, args)`` (model.py:2950) expects."""
+    sp2 = torch.sparse_coo_tensor(torch.stack([adj2.row, adj2.col]), torch.ones(adj2.nnz), (adj.n_rows, adj.n_cols))
+    sp1 = torch.sparse_coo_tensor(torch.stack([adj.row, adj.col]), torch.ones(adj.nnz), (adj.n_rows, adj.n_cols))
+    prod = torch.sparse.mm(sp2, sp1).coalesce()
+    idx = prod.indices()
+    return SpM(idx[0].contiguous(), idx[1].contiguous(), None, adj.n_rows, adj.n_cols)
+
+
+def cn6_pool(x: Tensor, cn1: SpM, cn2: SpM, cn3: SpM, innerprod: Tensor):
+    """model.py:2546-2940 in eval mode (``innerprod1`` returns the stored buffer three times):
+    stage 1 = cn5's normalise / orthogonalise / normalise of (cn1, cn2); stage 2 orthogonalises cn3
+    against BOTH normalised matrices over the union pattern and column-normalises it."""
+    xcn1, xcn2, aux = cn5_pool(x, cn1, cn2, innerprod)            # :2546-2714 == cn5 :2261-2427
+    ncn1, ncn2 = aux["ncn1"], aux["ncn2"]
+    B, N = cn1.n_rows, cn1.n_cols
+    sp_ncn1 = torch.sparse_coo_tensor(torch.stack([ncn1.row, ncn1.col]), ncn1.val, (B, N)).coalesce()   # :2734-2748
+    sp_ncn2 = torch.sparse_coo_tensor(torch.stack([ncn2.row, ncn2.col]), ncn2.val, (B, N)).coalesce()
+    sp_cn3 = torch.sparse_coo_tensor(torch.stack([cn3.row, cn3.col]), cn3.val, (B, N)).coalesce()
+    i3, i1, i2 = sp_cn3.indices(), sp_ncn1.indices(), sp_ncn2.indices()                                  # :2846-2852
+    uniq, inv = torch.unique(torch.cat((i3, i1, i2), dim=1), dim=1, return_inverse=True)                 # :2860-2866
+    a3 = torch.zeros(uniq.size(1))
+    a3[inv[:i3.size(1)]] = sp_cn3.values()                                                               # :2868-2869
+    a1 = torch.zeros(uniq.size(1))
+    a1[inv[i3.size(1):i3.size(1) + i1.size(1)]] = sp_ncn1.values()                                       # :2871-2875
+    a2 = torch.zeros(uniq.size(1))
+    a2[inv[i3.size(1) + i1.size(1):]] = sp_ncn2.values()                                                 # :2877-2881
+    scale = a1.abs().max().item() if a1.numel() > 0 else 1.0                                             # :2883-2886
+    nip1 = innerprod / scale if scale > 0 else innerprod                                                 # :2888-2893
+    nip2 = innerprod / scale if scale > 0 else innerprod
+    newv = a3 - nip1 * a1 - nip2 * a2                                                                    # :2895-2899
+    sp3 = torch.sparse_coo_tensor(uniq, newv, (B, N)).coalesce()                                         # :2901-2907
+    idx, vals = sp3.indices(), sp3.values()
+    S3 = torch.zeros(N).index_add_(0, idx[1], vals)                                                      # :2912-2913
+    S3[S3 == 0] = 1                                                                                      # :2917
+    inv3 = 1 / S3
+    ncn3 = SpM(idx[0], idx[1], vals * inv3[idx[1]], B, N)                                                # :2921-2931
+    xcn3 = spmm_add(ncn3, x)                                                                             # :2933
+    aux = dict(aux, S3=S3, ncn3=ncn3, scale2=scale)
+    return xcn1, xcn2, xcn3, aux
+
+
+def cn6_forward(sd: Dict[str, Tensor], x: Tensor, cn1: SpM, cn2: SpM, cn3: SpM, tar_ei: Tensor,
+                ln: bool = False, tailact: bool = False, twolayerlin: bool = False) -> Tensor:
+    """model.py:2934-2947: four branches, alpha has three live entries."""
+    xcn1, xcn2, xcn3, _ = cn6_pool(x, cn1, cn2, cn3, sd["innerprod"])
+    xij = _seq(sd, "xijlin", x[tar_ei[0]] * x[tar_ei[1]], _xij_layout(ln, tailact))
+    xcn1 = _seq(sd, "xcn1lin", xcn1, _xcn_layout(ln))
+    xcn2 = _seq(sd, "xcn2lin", xcn2, _xcn_layout(ln))
+    xcn3 = _seq(sd, "xcn3lin", xcn3, _xcn_layout(ln))
+    alpha = torch.sigmoid(sd["alpha"]).cumprod(-1)
+    z = alpha[0] * xcn1 + alpha[1] * xcn2 + alpha[2] * xcn3 + sd["beta"] * xij
+    return _seq(sd, "lin", z, _lin_layout(ln, twolayerlin))
+
+
+# ----------------------------------------------------------------------------
 # cn7 = CNLinkPredictorbaselearn.multidomainforward, eval (model.py:3102-3226)
 # ----------------------------------------------------------------------------
 def cn7_pool(x: Tensor, cn1: SpM, cn2: SpM, sum_fill: float):

@@ -96,6 +96,15 @@ def test_predictor_signatures_and_state_dict_keys():
     def keys(**kw):
         return set(predictor_dict["cn5"](16, 16, 1, 3, 0.1, 0.0, **kw).state_dict())
 
+    c6 = predictor_dict["cn6"]                                                             # model.py:2445-2458, 2950
+    assert list(inspect.signature(c6.__init__).parameters)[1:] == ctor
+    assert list(inspect.signature(c6.forward).parameters)[1:] == ["x", "adj", "cn1", "cn2", "cn3", "tar_ei", "args"]
+    assert list(inspect.signature(c6.multidomainforward).parameters)[1:] == [
+        "x", "adj", "cn1", "cn2", "cn3", "tar_ei", "args", "cndropprobs"]
+    k6 = set(c6(16, 16, 1, 3, 0.1, 0.0, True).state_dict())
+    assert {"xcn3lin.0.weight", "xcn3lin.3.bias", "xcn3lin.4.weight", "xcn3lin.7.weight"} <= k6
+    assert not any(k.startswith("xcn4lin") for k in k6) and "alpha" in k6 and "innerprod" in k6
+
     base = keys()
     lin = lambda p, idx: {f"{p}.{i}.{s}" for i in idx for s in ("weight", "bias")}
     want = ({"beta", "alpha", "innerprod", "dropadj.ratio"} | lin("xcnlin", (0, 3, 7)) | lin("xcn1lin", (0, 3, 7))

@@ -89,6 +89,36 @@ def test_oracle_vs_naive_model(seed):
     assert np.abs(a.numpy() - na).max() < 1e-5 and np.abs(b.numpy() - nbb).max() < 1e-4
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_cn6_oracle_vs_naive_model(seed):
+    """3-hop predictor (model.py:2535-2951): the op-for-op restatement against the set-based model."""
+    n, B, H = 120 + 30 * seed, 90, 10
+    ei = chung_lu_graph(n, 5, 30, seed=seed + 20, clique_frac=0.4)
+    adj = O.to_symmetric(O.from_edge_index(ei, n))
+    a2 = O.adj2_sparse(adj)
+    a3 = O.adj3_sparse(adj, a2)
+    e = sample_edges(adj.row, adj.col, n, B, seed=seed + 3)
+    nb = NM.neighbours(n, ei.t().tolist())
+    nb2 = NM.two_hop(nb)
+    nb3 = NM.three_hop(nb, nb2)
+    assert sorted((j, k) for j in range(n) for k in nb3[j]) == list(zip(a3.row.tolist(), a3.col.tolist()))
+    batch = e.t().tolist()
+    s1, s2 = NM.cn_sets(nb, nb2, batch)
+    s3 = [sorted(nb[i] & nb3[j]) for i, j in batch]
+    cn1, cn2, cn3 = O.adjoverlap(adj, adj, e), O.adjoverlap(adj, a2, e), O.adjoverlap(adj, a3, e)
+    assert [c for r in s3 for c in r] == cn3.col.tolist()
+    x = torch.randn(n, H)
+    for ip in (0.0, 0.37, -1.5):
+        a, b, c, aux = O.cn6_pool(x, cn1, cn2, cn3, torch.tensor([ip]))
+        na, nbb, nc, naux = NM.cn6_pool(n, x.numpy(), s1, s2, s3, ip)
+        assert np.abs(a.numpy() - na).max() < 1e-5
+        assert np.abs(b.numpy() - nbb).max() < 1e-4 * max(1.0, np.abs(nbb).max())
+        assert np.abs(c.numpy() - nc).max() < 2e-4 * max(1.0, np.abs(nc).max())
+        if ip == 0.0:       # fresh model: S3 = column counts of cn3
+            assert aux["S3"].tolist() == np.where(naux["S3"] == 0, 1.0, naux["S3"]).tolist()
+            assert aux["S3"].tolist() == torch.bincount(cn3.col, minlength=n).clamp(min=1).float().tolist()
+
+
 def test_adjoverlap_edge_cases():
     n = 30
     adj = O.to_symmetric(O.from_edge_index(torch.tensor([[0, 1, 2, 3], [1, 2, 3, 0]]), n))

@@ -694,3 +694,67 @@ def test_eval_caches_follow_parameter_updates(case):
     pred.xijlin[0].weight.data.mul_(0.5)     # bypasses the version counter ...
     pred.train(); pred.eval()                # ... but every pass starts with a mode switch
     assert close(run(), run_modules())
+
+
+# ---- cn6: the 3-hop predictor (model.py:2445-2951) ------------------------------
+@pytest.fixture(scope="module")
+def case3(hiplib):
+    from ocn_amd.sparse import SparseTensor
+    n, B = 1500, 1200
+    oadj = make_graph(n, 5, 60, 31, isolated=7)
+    oadj2 = O.adj2_sparse(oadj)
+    oadj3 = O.adj3_sparse(oadj, oadj2)
+    e = batch(oadj, B, 91)
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    adj3 = SparseTensor.from_torch_sparse_coo_tensor(adj2.to_torch_sparse_coo_tensor() @ adj.to_torch_sparse_coo_tensor(), False)
+    return SimpleNamespace(n=n, B=B, oadj=oadj, oadj2=oadj2, oadj3=oadj3, e=e, adj=adj, adj2=adj2, adj3=adj3,
+                           ocn=[O.adjoverlap(oadj, t, e) for t in (oadj, oadj2, oadj3)])
+
+
+def test_cn6_counts_and_pools(case3):
+    from ocn_amd.utils import CNState3, adjoverlap
+    c = case3
+    assert c.adj3.nnz() == c.oadj3.nnz and spm_equal(c.adj3, c.oadj3)
+    ed = c.e.to(DEV)
+    h3 = adjoverlap(c.adj, c.adj3, ed)
+    assert h3.counts().cpu().tolist() == torch.bincount(c.ocn[2].row, minlength=c.B).tolist()
+    assert spm_equal(h3.materialize(), c.ocn[2])
+    x = torch.randn(c.n, 64, generator=torch.Generator().manual_seed(2))
+    for ip in (0.0, 0.37):
+        r1, r2, r3, aux = O.cn6_pool(x, *c.ocn, torch.tensor([ip]))
+        st = CNState3(c.adj, c.adj2, c.adj3, ed)
+        assert st.cnt3.cpu().tolist() == torch.bincount(c.ocn[2].row, minlength=c.B).tolist()
+        wa, wb, nip = st.weights(torch.tensor([ip], device=DEV))
+        assert nip.item() == pytest.approx(float(aux["nip"]), rel=1e-6, abs=1e-12)
+        g1, g2, g3, gx = st.gather(wa, wb, nip, x.to(DEV))
+        assert torch.equal(gx.cpu(), x[c.e[0]] * x[c.e[1]])
+        if ip == 0.0:                     # integer column sums: every pooled vector in the oracle's order, bit for bit
+            assert torch.equal(g1.cpu(), r1) and torch.equal(g2.cpu(), r2) and torch.equal(g3.cpu(), r3)
+        else:
+            assert close(g1, r1)
+            for g, r in ((g2, r2), (g3, r3)):
+                assert (g.cpu() - r).abs().max().item() <= 2e-4 * max(1.0, r.abs().max().item())
+
+
+@pytest.mark.parametrize("H,ln", [(32, True), (256, True), (64, False)])
+def test_cn6_scores(case3, H, ln):
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    c = case3
+    torch.manual_seed(13)
+    x = torch.randn(c.n, H)
+    pred = predictor_dict["cn6"](H, H, 1, 3, 0.1, 0.0, ln, use_xlin=True, tailact=True, beta=0.7).eval()
+    with torch.no_grad():
+        pred.alpha.copy_(torch.tensor([0.3, -0.2, 0.9]))
+    sd = {k: v.detach().clone() for k, v in pred.state_dict().items()}
+    assert "xcn3lin.0.weight" in sd and not any(k.startswith("xcn4lin") for k in sd)
+    ref = O.cn6_forward(sd, x, *c.ocn, c.e, ln, True)
+    ed = c.e.to(DEV)
+    with torch.no_grad():
+        out = pred.to(DEV)(x.to(DEV), c.adj, adjoverlap(c.adj, c.adj, ed), adjoverlap(c.adj, c.adj2, ed),
+                           adjoverlap(c.adj, c.adj3, ed), ed, None)
+    assert out.shape == (c.B, 1) and close(out, ref), (out.cpu() - ref).abs().max()
+    with pytest.raises(NotImplementedError):
+        pred.train()(x.to(DEV), c.adj, adjoverlap(c.adj, c.adj, ed), adjoverlap(c.adj, c.adj2, ed),
+                     adjoverlap(c.adj, c.adj3, ed), ed, None)
