@@ -87,6 +87,14 @@ def oracle_vectors():
                                       scale=float(aux["scale"]))
         xcn1, xcn2, _ = O.cn7_pool(x, cn1, cn2, 2.74)
         rec["cn7_sum2.74"] = dict(xcn1_row0=xcn1[0].tolist(), xcn2_row0=xcn2[0].tolist())
+        if n <= 300:                                   # the 3-hop predictor (cn6): A³ stays small here
+            adj3 = O.adj3_sparse(adj, adj2)
+            cn3 = O.adjoverlap(adj, adj3, edges)
+            rec["a3_nnz"] = adj3.nnz
+            rec["cn3_counts"] = torch.bincount(cn3.row, minlength=B).tolist()
+            for ip in (0.0, 0.37):
+                _, _, xcn3, aux = O.cn6_pool(x, cn1, cn2, cn3, torch.tensor([ip]))
+                rec[f"cn6_ip{ip}"] = dict(xcn3_sum=xcn3.double().sum().item(), xcn3_row0=xcn3[0].tolist())
         out.append(rec)
     return out
 

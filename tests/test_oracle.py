@@ -151,3 +151,26 @@ def test_adj2_by_block_matches_sparse_and_fold_quirk():
 def test_perm_batches_keeps_ragged_tail():
     b = O.perm_batches(10, 4)
     assert [x.tolist() for x in b] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
+
+
+def test_oracle_reproduces_its_committed_vectors():
+    """tests/golden/oracle_vectors.json are ORACLE outputs (regression vectors for the HIP path): the oracle
+    of today must still produce them."""
+    import json
+    import os
+    recs = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_vectors.json")))
+    for rec in recs[:2]:
+        n, H = rec["n"], rec["H"]
+        adj = O.to_symmetric(O.from_edge_index(torch.tensor(rec["edge_index"]), n))
+        adj2 = O.adj2_sparse(adj)
+        e = torch.tensor(rec["batch"])
+        x = torch.randn(n, H, generator=torch.Generator().manual_seed(rec["x_seed"]))
+        cn1, cn2 = O.adjoverlap(adj, adj, e), O.adjoverlap(adj, adj2, e)
+        assert torch.bincount(cn1.row, minlength=e.shape[1]).tolist() == rec["cn1_counts"]
+        a, b, _ = O.cn5_pool(x, cn1, cn2, torch.tensor([0.37]))
+        assert a[0].tolist() == rec["cn5_ip0.37"]["xcn1_row0"] and b[0].tolist() == rec["cn5_ip0.37"]["xcn2_row0"]
+        adj3 = O.adj3_sparse(adj, adj2)
+        cn3 = O.adjoverlap(adj, adj3, e)
+        assert adj3.nnz == rec["a3_nnz"] and torch.bincount(cn3.row, minlength=e.shape[1]).tolist() == rec["cn3_counts"]
+        c = O.cn6_pool(x, cn1, cn2, cn3, torch.tensor([0.37]))[2]
+        assert c[0].tolist() == rec["cn6_ip0.37"]["xcn3_row0"]

@@ -256,6 +256,18 @@ def test_oracle_vectors_regression(hiplib):
         g1, g2, _ = st.gather(st.weights_cn7(2.74), x)
         assert g1[0].cpu().tolist() == pytest.approx(rec["cn7_sum2.74"]["xcn1_row0"], rel=1e-6, abs=1e-6)
         assert g2[0].cpu().tolist() == pytest.approx(rec["cn7_sum2.74"]["xcn2_row0"], rel=1e-6, abs=1e-6)
+        if "a3_nnz" in rec:
+            from ocn_amd.utils import CNState3
+            adj3 = SparseTensor.from_torch_sparse_coo_tensor(
+                adj2.to_torch_sparse_coo_tensor() @ adj.to_torch_sparse_coo_tensor(), False)
+            assert adj3.nnz() == rec["a3_nnz"]
+            for ip in (0.0, 0.37):
+                st3 = CNState3(adj, adj2, adj3, e)
+                assert st3.cnt3.cpu().tolist() == rec["cn3_counts"]
+                g = st3.gather(*st3.weights(torch.tensor([ip], device=DEV)), x)[2]
+                want = rec[f"cn6_ip{ip}"]
+                scale = max(1.0, max(abs(v) for v in want["xcn3_row0"]))
+                assert g[0].cpu().tolist() == pytest.approx(want["xcn3_row0"], rel=1e-5, abs=(1e-6 if ip == 0.0 else 2e-4 * scale))
 
 
 # ---- edge cases ---------------------------------------------------------------------------
