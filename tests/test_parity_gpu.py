@@ -256,7 +256,7 @@ def test_oracle_vectors_regression(hiplib):
         g1, g2, _ = st.gather(st.weights_cn7(2.74), x)
         assert g1[0].cpu().tolist() == pytest.approx(rec["cn7_sum2.74"]["xcn1_row0"], rel=1e-6, abs=1e-6)
         assert g2[0].cpu().tolist() == pytest.approx(rec["cn7_sum2.74"]["xcn2_row0"], rel=1e-6, abs=1e-6)
-        if "a3_nnz" in rec:
+        if "a3_nnz" in rec and H in (16, 32, 64, 128, 256, 512):      # ocn_cn_gather3's widths
             from ocn_amd.utils import CNState3
             adj3 = SparseTensor.from_torch_sparse_coo_tensor(
                 adj2.to_torch_sparse_coo_tensor() @ adj.to_torch_sparse_coo_tensor(), False)
