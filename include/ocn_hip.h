@@ -59,6 +59,20 @@ int ocn_order_by_node(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* 
 int ocn_chunk_offsets(const int64_t* rowptrA, const int64_t* nds /* or NULL */, const int64_t* src,
                       const int64_t* order, int64_t B, int64_t* out, void* workspace, void* stream);
 
+/* Class-major processing order for the MLP heads.  A candidate with no cn1 (cn2) entry has an all-zero
+ * pooled xcn1 (xcn2), and a zero row through `xcn1lin` is the same constant vector for every such
+ * candidate: sorted by class = (cnt1 > 0, cnt2 > 0) — 3 both, 2 cn1 only, 1 cn2 only, 0 none; stable, so
+ * the order inside a class is that of `order_in` (or batch order) — the heads run on contiguous row
+ * ranges and skip the rest (62 % / 47 % of a collab-shaped evaluation batch have no cn1 / cn2 entry).
+ * order_out[slot] = batch row, inv_out[batch row] = slot; ranges[OCN_CLASS_RANGES][2] = {begin, end} of
+ *   0: cn1 > 0   1: both   2: cn2 only   3: any   4: none   5: cn1 only   6: all rows
+ * (device-resident: OcnLinearGroup.row_range points into it, no host sync).  prefix: int64[B+1] scratch;
+ * workspace: ocn_scan_workspace_bytes(B). */
+#define OCN_CLASS_RANGES 7
+int ocn_class_order(const int32_t* cnt1, const int32_t* cnt2 /* or NULL */, const int64_t* order_in /* or NULL */,
+                    int64_t B, int64_t* order_out, int64_t* inv_out, int64_t* ranges, int64_t* prefix,
+                    void* workspace, void* stream);
+
 /* Exclusive scan of int32 counts into int64 offsets (out[n] = total). */
 int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, void* stream);
 
@@ -134,12 +148,13 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream);
  * h is [N][H] row-major fp32; outputs [B][H].  max_row_len = longest row of A (upper bound):
  * batch rows whose source row exceeds 1024 entries are pooled by a whole workgroup, in 256*4/H
  * contiguous segments whose partial sums are added in segment order (everything else keeps the
- * strictly sequential ascending-column sum). */
+ * strictly sequential ascending-column sum).  out_row (or NULL): batch row e is written to row
+ * out_row[e] of the three outputs (ocn_class_order's inv_out: class-major rows for the heads). */
 int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA,
                   const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                   const int64_t* off, const uint8_t* flags, const int32_t* wc,
                   const float* weights /* [N][4] */, const float* h, int32_t H, int64_t max_row_len,
-                  float* xcn1, float* xcn2, float* xij, void* stream);
+                  float* xcn1, float* xcn2, float* xij, const int64_t* out_row, void* stream);
 
 /* The 3-hop predictor cn6 (model.py:2535-2951), pattern route.  Two intersection passes over the same
  * candidate batch — (A, A, A²) into flagsA / histA and (A, A³) into flagsB / histB (bit 0 = cn3 entry,
@@ -221,6 +236,11 @@ int ocn_combine3(const float* coef, const float* x1, const float* x2, const floa
  * Epilogue, in this order: + bias (or NULL); LayerNorm over the N columns with gamma/beta/eps (or
  * both NULL); ReLU if relu != 0; then either store Y[M][N], or — when dotw != NULL — the trailing
  * Linear(N -> 1) of `lin`: Y[M] = <row, dotw> + dotb[0]. */
+/* dst[row][0 .. n_cols) = vec[0 .. n_cols) for the rows of a device-side range (clamped to max_rows): the
+ * constant activations of the candidates whose pooled input is all zero (ocn_class_order). */
+int ocn_fill_rows(float* dst, int64_t ld, int32_t n_cols, const float* vec, const int64_t* row_range,
+                  int64_t max_rows, void* stream);
+
 typedef struct OcnLinearGroup {
   const float* X; int64_t ldX;       /* input [M][K], row stride in floats (0 = K) */
   int64_t M;
@@ -232,6 +252,12 @@ typedef struct OcnLinearGroup {
   const float* addend; int64_t ldAdd;/* [M][N] added last (row stride, 0 = N), or NULL */
   const float* dotw; const float* dotb;   /* trailing Linear(N -> 1): Y is [M]; or NULL */
   float* Y; int64_t ldY;             /* output rows, row stride in floats (0 = N) */
+  /* Rows [row_range[0], row_range[1]) of the M-row buffers only (device int64[2], clamped to [0, M]), or
+   * NULL for all M rows: the bounds stay on the device, e.g. the class boundaries of a batch sorted by
+   * "has common neighbours" (ocn_class_order) — no host sync to launch on a sub-range. */
+  const int64_t* row_range;
+  const int64_t* y_row_map;          /* dot epilogue only: Y[y_row_map[row]] instead of Y[row], or NULL */
+  int32_t add_bcast;                 /* != 0: addend is ONE row [N] added to every row */
 } OcnLinearGroup;
 
 int64_t ocn_linear_panel_bytes(int32_t N, int32_t K);
@@ -239,7 +265,7 @@ int ocn_linear_split_weight(const float* W, int32_t N, int32_t K, void* Wp, void
 int ocn_linear_bf16x6(const float* X, int64_t M, int32_t K, const void* Wp, int32_t N,
                       const float* bias, const float* gamma, const float* beta, float eps,
                       int32_t relu, const float* dotw, const float* dotb, float* Y, void* stream);
-/* Up to 3 independent Linear layers of the same (K, N) in ONE launch (e.g. the first layers of
+/* Up to 5 independent Linear layers of the same (K, N) in ONE launch (e.g. the first layers of
  * xcn1lin, xcn2lin and xijlin): more workgroups than CU slots, so one group's LayerNorm epilogue
  * overlaps another's MFMA loop, and strided outputs let two branches write the halves of a
  * [M][2N] buffer that a K = 2N Linear then consumes (the branch mix of model.py:2436 folded into

@@ -23,6 +23,7 @@ SIGNATURES = {
     "ocn_abi_version": (c_int32, []),
     "ocn_scan_workspace_bytes": (c_int64, [c_int64]),
     "ocn_edge_offsets": (c_int32, [_P, _P, c_int64, _P, _P, _P]),
+    "ocn_class_order": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "ocn_scan_i32": (c_int32, [_P, c_int64, _P, _P, _P]),
     "ocn_order_workspace_bytes": (c_int64, [c_int64]),
     "ocn_order_by_node": (c_int32, [_P, c_int64, c_int64, _P, _P, _P]),
@@ -36,7 +37,7 @@ SIGNATURES = {
     "ocn_walk_rev_offsets": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
     "ocn_cn_weights_cn5": (c_int32, [_P, c_int64, _P, _P, c_int32, _P]),
     "ocn_cn_weights_cn7": (c_int32, [_P, c_int64, c_float, _P]),
-    "ocn_cn_gather": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P]),
+    "ocn_cn_gather": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P, _P]),
     "ocn_cn_weights_cn6": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P]),
     "ocn_cn_gather3": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),
     "ocn_cn_gather_backward": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),
@@ -46,6 +47,7 @@ SIGNATURES = {
     "ocn_spgemm_pattern_count": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P]),
     "ocn_spgemm_pattern_fill": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, _P]),
     "ocn_rows_ln_relu": (c_int32, [_P, _P, _P, c_float, c_int32, c_int64, c_int32, _P, _P]),
+    "ocn_fill_rows": (c_int32, [_P, c_int64, c_int32, _P, _P, c_int64, _P]),
     "ocn_combine3": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P]),
     "ocn_linear_panel_bytes": (c_int64, [c_int32, c_int32]),
     "ocn_linear_split_weight": (c_int32, [_P, c_int32, c_int32, _P, _P]),
@@ -64,7 +66,8 @@ class OcnLinearGroup(ctypes.Structure):
     _fields_ = [("X", c_void_p), ("ldX", c_int64), ("M", c_int64), ("Wp", c_void_p), ("bias", c_void_p),
                 ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("relu", c_int32),
                 ("scale", c_void_p), ("addend", c_void_p), ("ldAdd", c_int64), ("dotw", c_void_p),
-                ("dotb", c_void_p), ("Y", c_void_p), ("ldY", c_int64)]
+                ("dotb", c_void_p), ("Y", c_void_p), ("ldY", c_int64), ("row_range", c_void_p),
+                ("y_row_map", c_void_p), ("add_bcast", c_int32)]
 
 
 def sources():

@@ -706,7 +706,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
-    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
+    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij,
+    const i64* __restrict__ out_row) {   // out_row[batch row] = output row (class-major heads), or NULL
   constexpr int GPW = OCN_WAVE / LPE;
   const int lane = threadIdx.x & 63;
   const int gl = lane % LPE;
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
   pool_range<LPE, NV>(0, da, a0, off[e], gl, gbase, colA, flags, wc, weights, h4, rowq, acc1, acc2);
-  pool_store<LPE, NV>(e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
+  pool_store<LPE, NV>(out_row ? out_row[e] : e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
 }
 
 // Small batches of narrow embeddings (ppa / citation2: B = 2048, H = 32..64) leave the packed kernel
@@ -745,7 +746,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_wave_kernel(
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
-    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
+    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij,
+    const i64* __restrict__ out_row) {   // out_row[batch row] = output row (class-major heads), or NULL
   constexpr int G = OCN_WAVE / LPE;
   constexpr int UNR = LPE;                  // G * UNR = 64 rows: a whole round in flight
   __shared__ float4 s_x[OCN_WPB][OCN_WAVE][LPE * NV];
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_wave_kernel(
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
-  if (g == 0) pool_store<LPE, NV>(e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
+  if (g == 0) pool_store<LPE, NV>(out_row ? out_row[e] : e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
 }
 
 // One workgroup per batch row whose source row is longer than LONG_ROW (hub sources): the 1024/LPE
@@ -845,7 +847,8 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
     const i64* __restrict__ src, const i64* __restrict__ dst, i64 B,
     const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
-    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
+    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij,
+    const i64* __restrict__ out_row) {   // out_row[batch row] = output row (class-major heads), or NULL
   constexpr int NG = LONG_THREADS / LPE;    // lane groups per workgroup
   __shared__ float4 s_part[NG][2][LPE * NV];
   const i64 e = blockIdx.x;
@@ -886,7 +889,7 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
       acc1[v] = t1;
       acc2[v] = t2;
     }
-    pool_store<LPE, NV>(e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
+    pool_store<LPE, NV>(out_row ? out_row[e] : e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
   }
 }
 
@@ -984,7 +987,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_generic(
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
-    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij) {
+    float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij,
+    const i64* __restrict__ out_row) {   // out_row[batch row] = output row (class-major heads), or NULL
   const int lane = threadIdx.x & 63;
   const i64 slot = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6);
   if (slot >= B) return;
@@ -1017,9 +1021,10 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_generic(
       }
     }
     if (fin) {
-      xcn1[e * H + ft] = acc1;
-      xcn2[e * H + ft] = acc2;
-      xij[e * H + ft] = __fmul_rn(h[i * H + ft], h[j * H + ft]);
+      const i64 oe = out_row ? out_row[e] : e;
+      xcn1[oe * H + ft] = acc1;
+      xcn2[oe * H + ft] = acc2;
+      xij[oe * H + ft] = __fmul_rn(h[i * H + ft], h[j * H + ft]);
     }
   }
 }
@@ -1099,7 +1104,7 @@ template <int LPE, int NV>
 static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
                           const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
                           const int32_t* wc, const float* weights, const float* h, int32_t H, int64_t max_row_len,
-                          float* xcn1, float* xcn2, float* xij, hipStream_t st) {
+                          float* xcn1, float* xcn2, float* xij, const int64_t* out_row, hipStream_t st) {
   const i64 epb = (i64)OCN_WPB * (OCN_WAVE / LPE);
   bool packed = true;
   if constexpr (LPE <= 16) {
@@ -1107,16 +1112,17 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
       hipLaunchKernelGGL((cn_gather_wave_kernel<LPE, NV>), dim3((unsigned)((B + OCN_WPB - 1) / OCN_WPB)),
                          dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst,
                          (const i64*)order, (i64)B, (const i64*)off, flags, wc, (const float4*)weights, h, (int)H,
-                         xcn1, xcn2, xij);
+                         xcn1, xcn2, xij, (const i64*)out_row);
       packed = false;
     }
   }
   if (packed)
     hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)), dim3(OCN_BLOCK), 0, st,
                        (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B,
-                       (const i64*)off, flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij);
+                       (const i64*)off, flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij,
+                       (const i64*)out_row);
 #define LONG_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, wc, \
-                  (const float4*)weights, h, (int)H, xcn1, xcn2, xij
+                  (const float4*)weights, h, (int)H, xcn1, xcn2, xij, (const i64*)out_row
   if (max_row_len > LONG_ROW) {
     if (B <= 4096) hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV, 1024>), dim3((unsigned)B), dim3(1024), 0, st, LONG_ARGS);
     else hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV, 256>), dim3((unsigned)B), dim3(256), 0, st, LONG_ARGS);
@@ -1249,14 +1255,14 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream) 
 }
 
 #define GATHER_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, (const i64*)off, \
-                    flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij
+                    flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij, (const i64*)out_row
 #define LAUNCH_GATHER(LPE, NV)                                                                      \
-  launch_gather<LPE, NV>(rowptrA, colA, src, dst, order, B, off, flags, wc, weights, h, H, max_row_len, xcn1, xcn2, xij, st)
+  launch_gather<LPE, NV>(rowptrA, colA, src, dst, order, B, off, flags, wc, weights, h, H, max_row_len, xcn1, xcn2, xij, out_row, st)
 
 int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
                   const int64_t* dst, const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
                   const int32_t* wc, const float* weights, const float* h, int32_t H,
-                  int64_t max_row_len, float* xcn1, float* xcn2, float* xij, void* stream) {
+                  int64_t max_row_len, float* xcn1, float* xcn2, float* xij, const int64_t* out_row, void* stream) {
   if (B < 0 || H <= 0) return OCN_EINVAL;
   if (B == 0) return 0;
   if (!rowptrA || !src || !dst || !off || !weights || !h || !xcn1 || !xcn2 || !xij) return OCN_EINVAL;

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void split_weight_kernel(const float* __
 
 // One launch can carry up to LIN_MAX_GROUPS independent Linear layers of the same (K, N): each
 // group has its own rows, weights and epilogue; workgroup tiles are numbered group after group.
-#define LIN_MAX_GROUPS 3
+#define LIN_MAX_GROUPS 5
 struct LinGroup {
   const float* X; i64 ldX; i64 M;            // input rows [M][K], row stride ldX floats
   const __bf16* Wp;                          // pre-split weight panel
@@ -82,7 +82,10 @@ struct LinGroup {
   const float* addend; i64 ldAdd;            // [M][N] tensor added last (or NULL)
   const float *dotw, *dotb;                  // trailing Linear(N -> 1): Y becomes [M]
   float* Y; i64 ldY;                         // output rows, row stride ldY floats
+  const i64* row_range;                      // device {begin, end} within [0, M], or NULL
+  const i64* y_row_map;                      // dot epilogue: destination row, or NULL
   float eps; int relu; int tiles;            // tiles = ceil(M / LIN_ROWS)
+  int add_bcast;
 };
 struct LinArgs { int n_groups; int K; LinGroup g[LIN_MAX_GROUPS]; };
 
@@ -96,7 +99,13 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(const LinAr
   while (gi + 1 < args.n_groups && tile >= args.g[gi].tiles) { tile -= args.g[gi].tiles; ++gi; }
   const LinGroup& G = args.g[gi];
   const float* __restrict__ X = G.X;
-  const i64 M = G.M;
+  i64 r_begin = 0, M = G.M;                               // rows [r_begin, M) of this group
+  if (G.row_range) {
+    const i64 rb = G.row_range[0], re = G.row_range[1];
+    r_begin = rb < 0 ? 0 : rb;
+    M = re < M ? re : M;
+  }
+  if (r_begin + (i64)tile * LIN_ROWS >= M) return;        // whole workgroup: nothing in this tile
   const int K = args.K;
   const float* __restrict__ bias = G.bias;
   const float* __restrict__ gamma = G.gamma;
@@ -108,7 +117,7 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(const LinAr
   const int relu = G.relu;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
-  const i64 row0 = (i64)tile * LIN_ROWS + 32 * w;
+  const i64 row0 = r_begin + (i64)tile * LIN_ROWS + 32 * w;
   i64 arow = row0 + r;
   if (arow >= M) arow = M - 1;                            // tail rows: load something valid, never store
   const float4* xrow = reinterpret_cast<const float4*>(X + arow * G.ldX + 8 * hh);
@@ -283,7 +292,7 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(const LinAr
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) d += __shfl_xor(d, o, OCN_WAVE);
       const i64 row = row0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      if (r == 0 && row < M) Y[row] = d + (dotb ? dotb[0] : 0.f);
+      if (r == 0 && row < M) Y[G.y_row_map ? G.y_row_map[row] : row] = d + (dotb ? dotb[0] : 0.f);
     }
     return;
   }
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(const LinAr
       float* yr = Y + row * G.ldY + r;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
-        yr[32 * t] = acc[t][i] + (G.addend ? G.addend[row * G.ldAdd + 32 * t + r] : 0.f);
+        yr[32 * t] = acc[t][i] + (G.addend ? G.addend[(G.add_bcast ? 0 : row * G.ldAdd) + 32 * t + r] : 0.f);
     }
   }
 #else
@@ -327,7 +336,7 @@ __global__ __launch_bounds__(OCN_BLOCK, 2) void linear_bf16x6_kernel(const LinAr
       if (row < M) {
         float4 v = t4[q];
         if (G.addend) {
-          const float4 ad = reinterpret_cast<const float4*>(G.addend + row * G.ldAdd)[q % (N / 4)];
+          const float4 ad = reinterpret_cast<const float4*>(G.addend + (G.add_bcast ? 0 : row * G.ldAdd))[q % (N / 4)];
           v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
         }
         reinterpret_cast<float4*>(Y + row * G.ldY)[q % (N / 4)] = v;
@@ -373,6 +382,7 @@ static int fill_group(LinGroup& g, const OcnLinearGroup& s, int K, int N) {
   g.bias = s.bias; g.gamma = s.gamma; g.beta = s.beta; g.scale = s.scale;
   g.addend = s.addend; g.ldAdd = ldA; g.dotw = s.dotw; g.dotb = s.dotb;
   g.Y = s.Y; g.ldY = ldY; g.eps = s.eps; g.relu = s.relu;
+  g.row_range = (const i64*)s.row_range; g.y_row_map = (const i64*)s.y_row_map; g.add_bcast = s.add_bcast;
   g.tiles = (int)((s.M + LIN_ROWS - 1) / LIN_ROWS);
   return 0;
 }

@@ -69,6 +69,22 @@ __global__ __launch_bounds__(OCN_BLOCK) void combine3_kernel(const float* __rest
   }
 }
 
+// dst[row][0 .. 4q) = vec for the rows of a device-side range (the constant activations of the candidates
+// whose pooled input is all zero)
+__global__ __launch_bounds__(OCN_BLOCK) void fill_rows_kernel(float* __restrict__ dst, i64 ld, int q,
+                                                              const float4* __restrict__ vec,
+                                                              const i64* __restrict__ row_range, i64 max_rows) {
+  i64 rb = row_range[0], re = row_range[1];
+  if (rb < 0) rb = 0;
+  if (re > max_rows) re = max_rows;
+  const i64 n = (re - rb) * q;
+  for (i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (i64)gridDim.x * blockDim.x) {
+    const i64 row = rb + t / q;
+    const int c = (int)(t % q);
+    reinterpret_cast<float4*>(dst + row * ld)[c] = vec[c];
+  }
+}
+
 extern "C" {
 
 #define LAUNCH_LN(LPE, NV)                                                                          \
@@ -93,6 +109,18 @@ int ocn_rows_ln_relu(const float* x, const float* gamma, const float* beta, floa
     case 512: LAUNCH_LN(64, 2); break;
     default: return OCN_EINVAL;
   }
+  return launch_status();
+}
+
+int ocn_fill_rows(float* dst, int64_t ld, int32_t n_cols, const float* vec, const int64_t* row_range,
+                  int64_t max_rows, void* stream) {
+  if (max_rows < 0 || n_cols <= 0 || (n_cols & 3) || ld < n_cols || (ld & 3)) return OCN_EINVAL;
+  if (max_rows == 0) return 0;
+  if (!dst || !vec || !row_range) return OCN_EINVAL;
+  const i64 q = n_cols >> 2;
+  hipLaunchKernelGGL(fill_rows_kernel, dim3(grid_for((max_rows * q + OCN_BLOCK - 1) / OCN_BLOCK, 2048)),
+                     dim3(OCN_BLOCK), 0, (hipStream_t)stream, dst, (i64)ld, (int)q, (const float4*)vec,
+                     (const i64*)row_range, (i64)max_rows);
   return launch_status();
 }
 

@@ -41,6 +41,45 @@ struct RevChunksOfSlot {   // reverse-sweep work items of a batch row: ceil(deg(
     return walk_reverse(nds, i, j, di, dj) ? (dj + WALK_REV_CHUNK - 1) / WALK_REV_CHUNK : 0;
   }
 };
+// class of a batch row for the heads: 3 = cn1 and cn2 entries, 2 = cn1 only, 1 = cn2 only, 0 = none; the
+// scan carries the three non-zero classes' running counts in 21-bit fields of one word
+#define CLS_BITS 21
+#define CLS_MASK ((1ll << CLS_BITS) - 1)
+struct ClassOfSlot {
+  const int32_t* cnt1;
+  const int32_t* cnt2;
+  const i64* order;
+  __device__ __forceinline__ int cls(i64 slot) const {
+    const i64 e = order ? order[slot] : slot;
+    return (cnt1[e] > 0 ? 2 : 0) | ((cnt2 && cnt2[e] > 0) ? 1 : 0);
+  }
+  __device__ __forceinline__ i64 operator()(i64 slot) const {
+    const int c = cls(slot);
+    return c == 3 ? 1ll : (c == 2 ? (1ll << CLS_BITS) : (c == 1 ? (1ll << (2 * CLS_BITS)) : 0ll));
+  }
+};
+
+__global__ __launch_bounds__(OCN_BLOCK) void class_scatter(ClassOfSlot op, i64 B, const i64* __restrict__ prefix,
+                                                           i64* __restrict__ order_out, i64* __restrict__ inv_out,
+                                                           i64* __restrict__ ranges) {
+  const i64 tot = prefix[B];
+  const i64 n3 = tot & CLS_MASK, n2 = (tot >> CLS_BITS) & CLS_MASK, n1 = (tot >> (2 * CLS_BITS)) & CLS_MASK;
+  for (i64 slot = (i64)blockIdx.x * blockDim.x + threadIdx.x; slot < B; slot += (i64)gridDim.x * blockDim.x) {
+    const i64 p = prefix[slot];
+    const i64 b3 = p & CLS_MASK, b2 = (p >> CLS_BITS) & CLS_MASK, b1 = (p >> (2 * CLS_BITS)) & CLS_MASK;
+    const int c = op.cls(slot);
+    const i64 pos = c == 3 ? b3 : (c == 2 ? n3 + b2 : (c == 1 ? n3 + n2 + b1 : n3 + n2 + n1 + (slot - b3 - b2 - b1)));
+    const i64 e = op.order ? op.order[slot] : slot;
+    order_out[pos] = e;
+    inv_out[e] = pos;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const i64 m3 = n3, m32 = n3 + n2, m321 = n3 + n2 + n1;
+    const i64 r[OCN_CLASS_RANGES][2] = {{0, m32}, {0, m3}, {m32, m321}, {0, m321}, {m321, B}, {m3, m32}, {0, B}};
+    for (int q = 0; q < OCN_CLASS_RANGES; ++q) { ranges[2 * q] = r[q][0]; ranges[2 * q + 1] = r[q][1]; }
+  }
+}
+
 struct I32In {
   const int32_t* in;
   __device__ __forceinline__ i64 operator()(i64 e) const { return (i64)in[e]; }
@@ -227,6 +266,18 @@ int ocn_walk_rev_offsets(const int64_t* rowptrA, const int64_t* nds, const int64
   if (!rowptrA || !nds || ((!src || !dst) && B > 0)) return OCN_EINVAL;
   RevChunksOfSlot op{(const i64*)rowptrA, (const i64*)nds, (const i64*)src, (const i64*)dst, (const i64*)order};
   return run_scan(op, B, (i64*)out, workspace, (hipStream_t)stream);
+}
+
+int ocn_class_order(const int32_t* cnt1, const int32_t* cnt2, const int64_t* order_in, int64_t B,
+                    int64_t* order_out, int64_t* inv_out, int64_t* ranges, int64_t* prefix, void* workspace,
+                    void* stream) {
+  if (B < 0 || B > (int64_t)CLS_MASK || !ranges || (B > 0 && (!cnt1 || !order_out || !inv_out || !prefix))) return OCN_EINVAL;
+  ClassOfSlot op{cnt1, cnt2, (const i64*)order_in};
+  const int rc = run_scan(op, (i64)B, (i64*)prefix, workspace, (hipStream_t)stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(class_scatter, dim3(grid_for((B + OCN_BLOCK - 1) / OCN_BLOCK, 1024)), dim3(OCN_BLOCK), 0,
+                     (hipStream_t)stream, op, (i64)B, (const i64*)prefix, (i64*)order_out, (i64*)inv_out, (i64*)ranges);
+  return launch_status();
 }
 
 int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, void* stream) {

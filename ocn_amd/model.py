@@ -349,7 +349,7 @@ def _grp(x, st, y, **extra):
     return g
 
 
-def _seq_eval(seq: nn.Sequential, x: Tensor) -> Tensor:
+def _seq_eval(seq: nn.Sequential, x: Tensor, y_row_map: Optional[Tensor] = None) -> Tensor:
     """Eval-mode walk of one of the predictor's ``nn.Sequential`` heads.  Dropout/Identity vanish;
     ``Linear [-> LayerNorm] [-> ReLU] [-> Linear(H, 1)]`` runs as one bf16x6 MFMA kernel with the
     tail fused into its epilogue; anything that does not fit falls back to the module itself (the
@@ -371,7 +371,7 @@ def _seq_eval(seq: nn.Sequential, x: Tensor) -> Tensor:
                     and mods[j].in_features == m.out_features):
                 dot = (mods[j].weight, mods[j].bias)
                 j += 1
-            x = ops.linear(x, m.weight, m.bias, ln, relu, dot)
+            x = ops.linear(x, m.weight, m.bias, ln, relu, dot, y_row_map=y_row_map if dot is not None else None)
             i = j
         elif (isinstance(m, nn.LayerNorm) and m.elementwise_affine and x.dim() == 2
                 and x.shape[-1] in ops.LN_WIDTHS and x.is_contiguous()):
@@ -392,6 +392,7 @@ class _CNPredictorBase(nn.Module):
     """Parameters and MLP heads shared by cn5 and cn7 (model.py:2173-2239 ≡ 3023-3089).  The
     ``nn.Sequential`` layouts are part of the checkpoint contract (state_dict keys)."""
     cndeg: Final[int]
+    _xcn2_on_union = True          # pooled xcn2 lives on cn1 ∪ cn2 (cn5); cn7 overrides: raw cn2 only
 
     def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout, edrop=0.0,
                  ln=False, cndeg=-1, use_xlin=False, tailact=False, twolayerlin=False, beta=1.0):
@@ -450,7 +451,34 @@ class _CNPredictorBase(nn.Module):
         x = x.contiguous()
         if torch.is_grad_enabled() and x.requires_grad:
             return _PoolFn.apply(x, st, w)
+        st.cls = None
+        if (ops.skip_zero_rows and not self.training and not torch.is_grad_enabled() and st.B >= ops.skip_zero_min_batch
+                and st.cnt2 is not None and self._heads_plan(x.shape[1]) is not None):
+            # class-major rows: candidates without cn1 / cn2 entries end up in contiguous ranges the heads skip
+            # (the pooling keeps its own source-sorted, XCD-balanced processing order and only WRITES to the
+            # class-major rows: processed class-major, the XCDs holding the heavy classes ran 50 % longer)
+            st.cls = ops.class_order(st.cnt1, st.cnt2, st.order, st.ws)
+            return st.gather(w, x, out_row=st.cls[1])
         return st.gather(w, x)
+
+    def _heads_plan(self, H: int):
+        """Parsed stages of the four heads when the zero-row-skipping evaluation applies (3-layer pooled
+        heads ending in a plain Linear, 1- or 2-layer xijlin, `lin` ending in the fused Linear(H, 1) dot),
+        else None.  Cached per module structure."""
+        key = (H, ops.fast_linear)
+        if getattr(self, "_plan_key", None) != key:
+            plan = None
+            if H in ops.LINEAR_WIDTHS and ops.fast_linear:
+                sa, sb, sx = _stages(self.xcn1lin, H), _stages(self.xcn2lin, H), _stages(self.xijlin, H)
+                mods = [m for m in self.lin if not isinstance(m, (nn.Dropout, nn.Identity))]
+                tail_ok = (len(mods) >= 2 and isinstance(mods[-1], nn.Linear) and mods[-1].out_features == 1
+                           and mods[-1].in_features == H and _stages(nn.Sequential(*mods[:-1]), H) is not None)
+                if (sa is not None and sb is not None and sx is not None and len(sa) == 3 and len(sb) == 3
+                        and len(sx) in (1, 2) and sa[2][1] is None and not sa[2][2] and sb[2][1] is None
+                        and not sb[2][2] and tail_ok):
+                    plan = (sa, sb, sx)
+            self._plan, self._plan_key = plan, key
+        return self._plan
 
     def innerprod1(self, st):
         """model.py:2241-2250: in training the running mean of Σ(cn2 ⊙ ncn1) is updated and used;
@@ -470,6 +498,8 @@ class _CNPredictorBase(nn.Module):
         across a training pass."""
         self._coef_key = None
         self._mixw_key = None
+        self._zc_key = None
+        self._plan_key = None
         for p in self.parameters():
             ops._panels.pop(id(p), None)
         return super().train(mode)
@@ -496,6 +526,65 @@ class _CNPredictorBase(nn.Module):
                 self._mixb = (c[0] * la.bias + c[1] * lb.bias).contiguous()
             self._mixw_key = key
         return self._mixw, self._mixb
+
+    def _zero_consts(self, sa, sb, H: int, dev):
+        """What a candidate with an all-zero pooled xcn1 (xcn2) contributes: the activations after the second
+        layer of xcn1lin (xcn2lin) on a zero row, and the mix layer of the two — computed by the SAME
+        kernels on a one-row zero input, so a skipped row gets bit for bit what it would have computed.
+        Cached on the parameter versions."""
+        key = tuple((p.data_ptr(), p._version) for seq in (self.xcn1lin, self.xcn2lin) for p in seq.parameters()) \
+            + (self._mix_coef().data_ptr(), self._coef_key)
+        if getattr(self, "_zc_key", None) != key:
+            z1 = torch.zeros(1, H, device=dev)
+            t = torch.empty(2, 1, H, device=dev)
+            c2 = torch.empty(1, 2 * H, device=dev)
+            ops.linear_grouped([_grp(z1, sa[0], t[0]), _grp(z1, sb[0], t[1])], H, H)
+            ops.linear_grouped([_grp(t[0], sa[1], c2[:, :H]), _grp(t[1], sb[1], c2[:, H:])], H, H)
+            w3, b3 = self._mix_weight(sa[2][0], sb[2][0])
+            zc = torch.empty(1, H, device=dev)
+            ops.linear_grouped([dict(x=c2, weight=w3, bias=b3, relu=False, y=zc)], 2 * H, H)
+            self._zc = (c2[:, :H].contiguous(), c2[:, H:].contiguous(), zc)
+            self._zc_key = key
+        return self._zc
+
+    def _heads_skipping(self, xcn1, xcn2, xij, cls):
+        """The heads on class-major rows (ops.class_order): layer 1-2 of xcn1lin only where cnt1 > 0, of
+        xcn2lin only where cnt2 > 0, the mix layer only where either is, the constants elsewhere; `lin`
+        scatters the scores back to batch order."""
+        B, H = xij.shape
+        order2, _, r = cls
+        sa, sb, sx = self._heads_plan(H)
+        a2c, b2c, zc = self._zero_consts(sa, sb, H, xij.device)
+        coef = self._mix_coef()
+        dev = xij.device
+        two = len(sx) == 2
+        y0 = ops.buf(self._ws, "y0", (B, H), torch.float32, dev)
+        z = ops.buf(self._ws, "z", (B, H), torch.float32, dev)
+        t1 = ops.buf(self._ws, "t1", (3 if two else 2, B, H), torch.float32, dev)
+        cat = ops.buf(self._ws, "cat", (B, 2 * H), torch.float32, dev)
+        R = ops
+
+        def xij_last(x, st):         # beta * xijlin(..): into y0 where the mix layer runs, + zc straight into z elsewhere
+            return [_grp(x, st, y0, scale=coef[2:3], row_range=r[R.R_ANY]),
+                    _grp(x, st, z, scale=coef[2:3], row_range=r[R.R_NONE], addend=zc, add_bcast=True)]
+
+        # rows whose pooled xcn2 can be non-zero: cn5 orthogonalises cn2 against cn1 over the UNION pattern
+        # (a cn1-only entry carries -t*inv2 when innerprod != 0), cn7 pools the raw cn2
+        b_rows = [R.R_ANY] if self._xcn2_on_union else [R.R_BOTH, R.R_CN2_ONLY]
+        g1 = [_grp(xcn1, sa[0], t1[0], row_range=r[R.R_CN1])] + [_grp(xcn2, sb[0], t1[1], row_range=r[q]) for q in b_rows]
+        g1 += [_grp(xij, sx[0], t1[2])] if two else xij_last(xij, sx[0])
+        ops.linear_grouped(g1, H, H)
+        g2 = [_grp(t1[0], sa[1], cat[:, :H], row_range=r[R.R_CN1])] + \
+             [_grp(t1[1], sb[1], cat[:, H:], row_range=r[q]) for q in b_rows]
+        if two:
+            g2 += xij_last(t1[2], sx[1])
+        ops.linear_grouped(g2, H, H)
+        if not self._xcn2_on_union:
+            ops.fill_rows(cat[:, H:], b2c, r[R.R_CN1_ONLY])
+        ops.fill_rows(cat[:, :H], a2c, r[R.R_CN2_ONLY])
+        w3, b3 = self._mix_weight(sa[2][0], sb[2][0])
+        ops.linear_grouped([dict(x=cat, weight=w3, bias=b3, relu=False, y=z, addend=y0, row_range=r[R.R_ANY])], 2 * H, H)
+        return _seq_eval(self.lin, z, y_row_map=order2)
 
     def _heads_grouped(self, xcn1, xcn2, xij):
         """The three branches layer by layer instead of branch by branch: launch 1 = first layers of
@@ -532,7 +621,9 @@ class _CNPredictorBase(nn.Module):
         ops.linear_grouped([dict(x=cat, weight=w3, bias=b3, relu=False, y=z, addend=y0)], 2 * H, H)
         return z
 
-    def _heads(self, x, xcn1, xcn2, xij):
+    def _heads(self, x, xcn1, xcn2, xij, cls=None):
+        if cls is not None:
+            return self._heads_skipping(xcn1, xcn2, xij, cls)
         if self.training or torch.is_grad_enabled() or not xij.is_cuda or xij.shape[-1] % 4:
             alpha = torch.sigmoid(self.alpha).cumprod(-1)
             xij = self.xijlin(xij)
@@ -561,7 +652,7 @@ class CNLinkPredictorOringin(_CNPredictorBase):
         st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x)))
         w = st.weights_cn5(self.innerprod1(st))
         xcn1, xcn2, xij = self._pool(st, w, x)
-        return self._heads(x, xcn1, xcn2, xij)
+        return self._heads(x, xcn1, xcn2, xij, getattr(st, "cls", None))
 
     def forward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False):
         return self.multidomainforward(x, adj, cn1, cn2, tar_ei, filled1, [])
@@ -570,13 +661,14 @@ class CNLinkPredictorOringin(_CNPredictorBase):
 class CNLinkPredictorbaselearn(_CNPredictorBase):
     """cn7 (model.py:3021-3229): cn1 column-normalised with ``args.sum`` for columns hit fewer than
     twice, Chebyshev diagonal hard-wired to T0 = identity, raw cn2; same heads."""
+    _xcn2_on_union = False
 
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, args, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
         st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x)))
         w = st.weights_cn7(float(args.sum))
         xcn1, xcn2, xij = self._pool(st, w, x)
-        return self._heads(x, xcn1, xcn2, xij)
+        return self._heads(x, xcn1, xcn2, xij, getattr(st, "cls", None))
 
     def forward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False):
         # the drivers pass the argparse Namespace in this slot (NeighborOverlap_large.py:122)

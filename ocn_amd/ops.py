@@ -19,6 +19,8 @@ validate_indices = True          # bounds-check candidate edges on the host side
 stage_timer = None               # optional object with .mark(name): bench.py records HIP events between stages
 LN_WIDTHS = (16, 32, 64, 128, 256, 512)   # row widths of the lane-group kernels (LayerNorm, pooling backward)
 a2_bitmap_max_bytes = 16 << 30   # keep A·B also as dense bit rows when n_rows * n_cols / 8 fits this budget
+skip_zero_rows = True            # heads: skip the layers whose pooled input row is all zero (class-major rows)
+skip_zero_min_batch = 4096       # below this the extra small launches cost more than the skipped rows save
 walk_two_sided = True            # walk route: sweep each candidate from its cheaper endpoint (needs nds of the adjacency)
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 
@@ -207,7 +209,7 @@ def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
 
 
 def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights: Tensor, h: Tensor,
-              order: Optional[Tensor] = None, max_row_len: int = 0, wsd=None):
+              order: Optional[Tensor] = None, max_row_len: int = 0, wsd=None, out_row: Optional[Tensor] = None):
     _req(weights, torch.float32, "weights", 2)
     _req(h, torch.float32, "h", 2)
     if weights.shape[0] != h.shape[0] or weights.shape[1] != 4:
@@ -216,9 +218,29 @@ def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights
     out = buf(wsd, "pooled", (3, B, H), torch.float32, h.device)
     check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags),
                                    ptr(wc), ptr(weights), ptr(h), H, int(max_row_len), ptr(out[0]), ptr(out[1]),
-                                   ptr(out[2]), stream_ptr()), "ocn_cn_gather")
+                                   ptr(out[2]), ptr(out_row), stream_ptr()), "ocn_cn_gather")
     _mark("cn_gather")
     return out[0], out[1], out[2]
+
+
+CLASS_RANGES = 7                 # include/ocn_hip.h: OCN_CLASS_RANGES
+R_CN1, R_BOTH, R_CN2_ONLY, R_ANY, R_NONE, R_CN1_ONLY, R_ALL = range(CLASS_RANGES)
+
+
+def class_order(cnt1: Tensor, cnt2: Optional[Tensor], order: Optional[Tensor], wsd=None):
+    """Class-major processing order for the heads (ocn_hip.h: ocn_class_order).
+    Returns (order2 [B] slot -> batch row, inv [B] batch row -> slot, ranges int64 [7, 2] on the device)."""
+    _req(cnt1, torch.int32, "cnt1", 1)
+    B = cnt1.numel()
+    dev = cnt1.device
+    order2 = buf(wsd, "cls_order", B, torch.int64, dev)
+    inv = buf(wsd, "cls_inv", B, torch.int64, dev)
+    ranges = buf(wsd, "cls_ranges", (CLASS_RANGES, 2), torch.int64, dev)
+    prefix = buf(wsd, "cls_prefix", B + 1, torch.int64, dev)
+    ws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, dev)
+    check(_lib.lib().ocn_class_order(ptr(cnt1), ptr(cnt2), ptr(order), B, ptr(order2), ptr(inv), ptr(ranges),
+                                     ptr(prefix), ptr(ws), stream_ptr()), "ocn_class_order")
+    return order2, inv, ranges
 
 
 def cn_weights_cn6(histA: Tensor, histB: Tensor, innerprod: Tensor):
@@ -356,6 +378,18 @@ def combine3(coef: Tensor, x1: Tensor, x2: Tensor, x3: Tensor) -> Tensor:
     return out
 
 
+def fill_rows(dst: Tensor, vec: Tensor, row_range: Tensor) -> None:
+    """dst[rows of the device-side range] = vec (dst may be a column slice of a wider buffer)."""
+    _req_strided(dst, "dst")
+    _req(vec, torch.float32, "vec")
+    _req(row_range, torch.int64, "row_range", 1)
+    if vec.numel() != dst.shape[1]:
+        raise ValueError("fill_rows: width mismatch")
+    check(_lib.lib().ocn_fill_rows(ptr(dst), dst.stride(0), dst.shape[1], ptr(vec), ptr(row_range), dst.shape[0],
+                                   stream_ptr()), "ocn_fill_rows")
+    _mark("mlp_glue")
+
+
 LINEAR_WIDTHS = (32, 64, 128, 256)
 fast_linear = True               # route eligible nn.Linear layers of the heads through ocn_linear_bf16x6
 _panels: dict = {}
@@ -389,12 +423,20 @@ def linear_ok(x: Tensor, weight: Tensor) -> bool:
 
 
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln=None, relu: bool = False,
-           dot=None) -> Tensor:
+           dot=None, y_row_map: Optional[Tensor] = None) -> Tensor:
     """epilogue(x @ weight.T + bias): optional LayerNorm ``ln=(gamma, beta, eps)``, ReLU, and a
-    trailing Linear(N -> 1) ``dot=(w[1,N], b[1] | None)`` (then the result is [M, 1])."""
+    trailing Linear(N -> 1) ``dot=(w[1,N], b[1] | None)`` (then the result is [M, 1]; with
+    ``y_row_map`` row r of x lands in row y_row_map[r] of it)."""
     _req(x, torch.float32, "x", 2)
     M, K = x.shape
     N = weight.shape[0]
+    if y_row_map is not None:
+        if dot is None:
+            raise ValueError("y_row_map needs the dot epilogue")
+        y = torch.empty((M, 1), dtype=torch.float32, device=x.device)
+        linear_grouped([dict(x=x, weight=weight, bias=bias, ln=ln, relu=relu, dot=(dot[0].reshape(1, -1), dot[1]), y=y,
+                             y_row_map=y_row_map)], K, N)
+        return y
     panel = linear_panel(weight)
     _mark("mlp_glue")
     y = torch.empty((M, 1) if dot is not None else (M, N), dtype=torch.float32, device=x.device)
@@ -413,12 +455,13 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln=None, re
 
 
 def linear_grouped(groups, K: int, N: int) -> None:
-    """Up to three Linear layers of the same (K, N) in one launch.  Each group is a dict:
+    """Up to five Linear layers of the same (K, N) in one launch.  Each group is a dict:
     x [M, >=K] (row stride may exceed K), weight [N, K], y (preallocated, row stride >= N, or [M, 1] with
-    ``dot``), optional bias, ln=(gamma, beta, eps), relu, scale (device float[1]), addend [M, >=N],
-    dot=(w[1, N], b[1])."""
-    if not 1 <= len(groups) <= 3:
-        raise ValueError("1..3 groups")
+    ``dot``), optional bias, ln=(gamma, beta, eps), relu, scale (device float[1]), addend [M, >=N] (or one
+    row [1, N] with ``add_bcast``), dot=(w[1, N], b[1]), row_range (device int64[2]: only rows
+    [begin, end) of the buffers), y_row_map (device int64[M]: destination row of the dot output)."""
+    if not 1 <= len(groups) <= 5:
+        raise ValueError("1..5 groups")
     arr = (_lib.OcnLinearGroup * len(groups))()
     keep = []
     for a, g in zip(arr, groups):
@@ -439,6 +482,16 @@ def linear_grouped(groups, K: int, N: int) -> None:
         if add is not None:
             _req_strided(add, "addend")
             a.addend, a.ldAdd = add.data_ptr(), add.stride(0)
+            a.add_bcast = int(bool(g.get("add_bcast")))
+            if a.add_bcast and add.shape != (1, N):
+                raise ValueError("add_bcast: addend must be [1, N]")
+        rr, rm = g.get("row_range"), g.get("y_row_map")
+        if rr is not None:
+            _req(rr, torch.int64, "row_range", 1)
+            a.row_range = rr.data_ptr()
+        if rm is not None:
+            _req(rm, torch.int64, "y_row_map", 1)
+            a.y_row_map = rm.data_ptr()
         if dot is not None:
             a.dotw = dot[0].data_ptr()
             a.dotb = 0 if dot[1] is None else dot[1].data_ptr()

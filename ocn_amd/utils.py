@@ -90,10 +90,12 @@ class CNState:
         self._hist_live = False
         return ops.cn_weights_cn7(self.hist, sum_fill)
 
-    def gather(self, weights: Tensor, h: Tensor):
+    def gather(self, weights: Tensor, h: Tensor, order: Optional[Tensor] = None, out_row: Optional[Tensor] = None):
+        """(xcn1, xcn2, x_i * x_j); ``order`` overrides the processing order, ``out_row`` sends batch row e
+        to output row out_row[e] (class-major rows for the heads, ops.class_order)."""
         return ops.cn_gather(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off,
-                             self.flags, self.wc, weights, h, order=self.order,
-                             max_row_len=self.adj.max_rowcount(), wsd=self.ws)
+                             self.flags, self.wc, weights, h, order=self.order if order is None else order,
+                             max_row_len=self.adj.max_rowcount(), wsd=self.ws, out_row=out_row)
 
     def gather_backward(self, weights: Tensor, h: Tensor, g1: Tensor, g2: Tensor, g3: Tensor) -> Tensor:
         return ops.cn_gather_backward(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off, self.flags,

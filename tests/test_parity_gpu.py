@@ -770,3 +770,47 @@ def test_cn6_scores(case3, H, ln):
     with pytest.raises(NotImplementedError):
         pred.train()(x.to(DEV), c.adj, adjoverlap(c.adj, c.adj, ed), adjoverlap(c.adj, c.adj2, ed),
                      adjoverlap(c.adj, c.adj3, ed), ed, None)
+
+
+# ---- heads on class-major rows: skipping the all-zero pooled rows changes nothing ------------------
+@pytest.mark.parametrize("name,H,tailact,two", [("cn5", 256, True, False), ("cn7", 64, False, False), ("cn5", 128, True, True)])
+def test_zero_row_skipping_is_bitwise_neutral(hiplib, name, H, tailact, two):
+    from ocn_amd import ops
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import CNState, adjoverlap
+    n, B = 6000, 5003                                       # ragged: B is no multiple of the 128-row tile
+    oadj = make_graph(n, 6, 80, 41, isolated=30)
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    e = batch(oadj, B, 17).to(DEV)
+    st = CNState(adj, adj, adj2, e)
+    order2, inv, r = ops.class_order(st.cnt1, st.cnt2, st.order)
+    c1, c2 = st.cnt1.cpu() > 0, st.cnt2.cpu() > 0
+    cls = c1.long() * 2 + c2.long()
+    n3, n2, n1 = [(cls == c).sum().item() for c in (3, 2, 1)]
+    assert n3 > 0 and n1 > 0 and B - n3 - n2 - n1 > 0
+    assert r.cpu().tolist() == [[0, n3 + n2], [0, n3], [n3 + n2, n3 + n2 + n1], [0, n3 + n2 + n1], [n3 + n2 + n1, B],
+                                [n3, n3 + n2], [0, B]]
+    o = order2.cpu()
+    assert sorted(o.tolist()) == list(range(B)) and torch.equal(inv.cpu()[o], torch.arange(B))
+    assert cls[o].tolist() == sorted(cls.tolist(), reverse=True)            # class-major ...
+    where = torch.empty(B, dtype=torch.long)                                 # position in the incoming (source-sorted) order
+    where[st.order.cpu()] = torch.arange(B)
+    for c in (3, 1, 0):                                                      # ... and stable inside a class
+        pos = where[o[cls[o] == c]]
+        assert torch.equal(pos, pos.sort().values)
+    torch.manual_seed(3)
+    x = torch.randn(n, H, device=DEV)
+    pred = predictor_dict[name](H, H, 1, 3, 0.1, 0.0, True, use_xlin=True, tailact=tailact, twolayerlin=two, beta=0.6).to(DEV).eval()
+    if two:
+        pred.innerprod.fill_(7.5)        # trained cn5: cn1-only entries then carry weight in xcn2
+    args = SimpleNamespace(sum=1.3)
+    outs = []
+    for skip in (False, True):
+        ops.skip_zero_rows = skip
+        try:
+            with torch.no_grad():
+                outs.append(pred(x, adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e), e, args))
+        finally:
+            ops.skip_zero_rows = True
+    assert outs[0].shape == (B, 1) and torch.equal(outs[0], outs[1])
