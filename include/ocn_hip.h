@@ -149,12 +149,16 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream);
  * batch rows whose source row exceeds 1024 entries are pooled by a whole workgroup, in 256*4/H
  * contiguous segments whose partial sums are added in segment order (everything else keeps the
  * strictly sequential ascending-column sum).  out_row (or NULL): batch row e is written to row
- * out_row[e] of the three outputs (ocn_class_order's inv_out: class-major rows for the heads). */
+ * out_row[e] of the three outputs (ocn_class_order's inv_out: class-major rows for the heads).
+ * cnt1 / cnt2 (or NULL): the per-row CN counts of the intersection pass; a row with neither kind of
+ * entry is not walked at all, and with out_row the xcn1 / xcn2 rows the class-major heads never read
+ * (no cn1 entry; no entry at all) are not written. */
 int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA,
                   const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                   const int64_t* off, const uint8_t* flags, const int32_t* wc,
                   const float* weights /* [N][4] */, const float* h, int32_t H, int64_t max_row_len,
-                  float* xcn1, float* xcn2, float* xij, const int64_t* out_row, void* stream);
+                  float* xcn1, float* xcn2, float* xij, const int64_t* out_row,
+                  const int32_t* cnt1, const int32_t* cnt2, void* stream);
 
 /* The 3-hop predictor cn6 (model.py:2535-2951), pattern route.  Two intersection passes over the same
  * candidate batch — (A, A, A²) into flagsA / histA and (A, A³) into flagsB / histB (bit 0 = cn3 entry,

@@ -678,7 +678,7 @@ template <int LPE, int NV>
 __device__ __forceinline__ void pool_store(i64 e, i64 i, i64 j, int gl, const float4* __restrict__ h4, i64 rowq,
                                            const float4 (&acc1)[NV], const float4 (&acc2)[NV],
                                            float* __restrict__ xcn1, float* __restrict__ xcn2,
-                                           float* __restrict__ xij) {
+                                           float* __restrict__ xij, bool st1 = true, bool st2 = true) {
   const float4* hi = h4 + i * rowq + gl;
   const float4* hj = h4 + j * rowq + gl;
   float4* o1 = reinterpret_cast<float4*>(xcn1) + e * rowq + gl;
@@ -687,8 +687,8 @@ __device__ __forceinline__ void pool_store(i64 e, i64 i, i64 j, int gl, const fl
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     const float4 a = hi[v * LPE], b = hj[v * LPE];
-    o1[v * LPE] = acc1[v];
-    o2[v * LPE] = acc2[v];
+    if (st1) o1[v * LPE] = acc1[v];
+    if (st2) o2[v * LPE] = acc2[v];
     o3[v * LPE] = make_float4(__fmul_rn(a.x, b.x), __fmul_rn(a.y, b.y), __fmul_rn(a.z, b.z),
                               __fmul_rn(a.w, b.w));
   }
@@ -707,7 +707,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
     const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
     float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij,
-    const i64* __restrict__ out_row) {   // out_row[batch row] = output row (class-major heads), or NULL
+    const i64* __restrict__ out_row,     // out_row[batch row] = output row (class-major heads), or NULL
+    const int32_t* __restrict__ cnt1, const int32_t* __restrict__ cnt2) {   // per-row CN counts, or NULL
   constexpr int GPW = OCN_WAVE / LPE;
   const int lane = threadIdx.x & 63;
   const int gl = lane % LPE;
@@ -730,8 +731,12 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
   float4 acc1[NV], acc2[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  pool_range<LPE, NV>(0, da, a0, off[e], gl, gbase, colA, flags, wc, weights, h4, rowq, acc1, acc2);
-  pool_store<LPE, NV>(out_row ? out_row[e] : e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
+  // a candidate without any CN entry (half of an evaluation batch) has nothing to pool; with class-major
+  // output rows the heads never read its xcn1 / xcn2 rows (nor the xcn1 row of one without cn1 entries)
+  const bool has1 = !cnt1 || cnt1[e] > 0, has2 = !cnt2 || cnt2[e] > 0;
+  if (has1 | has2) pool_range<LPE, NV>(0, da, a0, off[e], gl, gbase, colA, flags, wc, weights, h4, rowq, acc1, acc2);
+  pool_store<LPE, NV>(out_row ? out_row[e] : e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij,
+                      !out_row || has1, !out_row || has1 || has2);
 }
 
 // Small batches of narrow embeddings (ppa / citation2: B = 2048, H = 32..64) leave the packed kernel
@@ -1104,7 +1109,8 @@ template <int LPE, int NV>
 static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
                           const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
                           const int32_t* wc, const float* weights, const float* h, int32_t H, int64_t max_row_len,
-                          float* xcn1, float* xcn2, float* xij, const int64_t* out_row, hipStream_t st) {
+                          float* xcn1, float* xcn2, float* xij, const int64_t* out_row, const int32_t* cnt1,
+                          const int32_t* cnt2, hipStream_t st) {
   const i64 epb = (i64)OCN_WPB * (OCN_WAVE / LPE);
   bool packed = true;
   if constexpr (LPE <= 16) {
@@ -1120,7 +1126,7 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
     hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)), dim3(OCN_BLOCK), 0, st,
                        (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B,
                        (const i64*)off, flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij,
-                       (const i64*)out_row);
+                       (const i64*)out_row, cnt1, cnt2);
 #define LONG_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, wc, \
                   (const float4*)weights, h, (int)H, xcn1, xcn2, xij, (const i64*)out_row
   if (max_row_len > LONG_ROW) {
@@ -1257,12 +1263,13 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream) 
 #define GATHER_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, (const i64*)off, \
                     flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij, (const i64*)out_row
 #define LAUNCH_GATHER(LPE, NV)                                                                      \
-  launch_gather<LPE, NV>(rowptrA, colA, src, dst, order, B, off, flags, wc, weights, h, H, max_row_len, xcn1, xcn2, xij, out_row, st)
+  launch_gather<LPE, NV>(rowptrA, colA, src, dst, order, B, off, flags, wc, weights, h, H, max_row_len, xcn1, xcn2, xij, out_row, cnt1, cnt2, st)
 
 int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
                   const int64_t* dst, const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
                   const int32_t* wc, const float* weights, const float* h, int32_t H,
-                  int64_t max_row_len, float* xcn1, float* xcn2, float* xij, const int64_t* out_row, void* stream) {
+                  int64_t max_row_len, float* xcn1, float* xcn2, float* xij, const int64_t* out_row,
+                  const int32_t* cnt1, const int32_t* cnt2, void* stream) {
   if (B < 0 || H <= 0) return OCN_EINVAL;
   if (B == 0) return 0;
   if (!rowptrA || !src || !dst || !off || !weights || !h || !xcn1 || !xcn2 || !xij) return OCN_EINVAL;

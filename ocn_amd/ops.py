@@ -209,7 +209,8 @@ def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
 
 
 def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights: Tensor, h: Tensor,
-              order: Optional[Tensor] = None, max_row_len: int = 0, wsd=None, out_row: Optional[Tensor] = None):
+              order: Optional[Tensor] = None, max_row_len: int = 0, wsd=None, out_row: Optional[Tensor] = None,
+              cnt1: Optional[Tensor] = None, cnt2: Optional[Tensor] = None):
     _req(weights, torch.float32, "weights", 2)
     _req(h, torch.float32, "h", 2)
     if weights.shape[0] != h.shape[0] or weights.shape[1] != 4:
@@ -218,7 +219,7 @@ def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights
     out = buf(wsd, "pooled", (3, B, H), torch.float32, h.device)
     check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags),
                                    ptr(wc), ptr(weights), ptr(h), H, int(max_row_len), ptr(out[0]), ptr(out[1]),
-                                   ptr(out[2]), ptr(out_row), stream_ptr()), "ocn_cn_gather")
+                                   ptr(out[2]), ptr(out_row), ptr(cnt1), ptr(cnt2), stream_ptr()), "ocn_cn_gather")
     _mark("cn_gather")
     return out[0], out[1], out[2]
 

@@ -95,7 +95,8 @@ class CNState:
         to output row out_row[e] (class-major rows for the heads, ops.class_order)."""
         return ops.cn_gather(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off,
                              self.flags, self.wc, weights, h, order=self.order if order is None else order,
-                             max_row_len=self.adj.max_rowcount(), wsd=self.ws, out_row=out_row)
+                             max_row_len=self.adj.max_rowcount(), wsd=self.ws, out_row=out_row,
+                             cnt1=self.cnt1, cnt2=self.cnt2)
 
     def gather_backward(self, weights: Tensor, h: Tensor, g1: Tensor, g2: Tensor, g3: Tensor) -> Tensor:
         return ops.cn_gather_backward(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off, self.flags,
