@@ -340,8 +340,21 @@ def main():
                             note="algorithmic bytes price one embedding row per CN entry; rows shared by "
                                  "candidates processed together are served by L2, so frac can exceed 1")
             if dom == "linear":
-                # algorithmic f32 FLOPs of the Linear layers in the sampled steps / their launches
+                # f32 FLOPs of the Linear layers per launch.  With the zero-row skipping of the heads the
+                # launches cover only part of the batch (device-side row ranges): count the rows they do.
                 fl = timer.flops.get("linear", 0.0) / stages["linear"]["launches"]
+                skip = getattr(pred, "_skip_state", None)
+                skipping = bool(ops.skip_zero_rows and skip is not None and skip["off"] == 0
+                                and mine.shape[1] >= ops.skip_zero_min_batch and pred._heads_plan(H) is not None)
+                if skipping:
+                    Bm = mine.shape[1]
+                    n_cn1 = int((st.cnt1 > 0).sum())
+                    n_any = int(((st.cnt1 > 0) | (st.cnt2 > 0)).sum())
+                    n_b = n_any if pred._xcn2_on_union else int((st.cnt2 > 0).sum())
+                    sx_layers = len(pred._heads_plan(H)[2])
+                    lin_layers = sum(1 for m in pred.lin if isinstance(m, torch.nn.Linear) and m.out_features == H)
+                    executed = 2.0 * H * H * (2 * n_cn1 + 2 * n_b + sx_layers * Bm + lin_layers * Bm) + 2.0 * (2 * H) * H * n_any
+                    fl = executed / (stages["linear"]["launches"] / sampled)
                 t = stages["linear"]["ms"] * 1e-3
                 roof = dict(bound="mfma", kernel="linear_bf16x6_kernel", achieved=fl / t / 1e12,
                             peak=F32_MFMA_PEAK / 1e12, unit="TFLOP/s", frac=fl / t / F32_MFMA_PEAK,
@@ -349,8 +362,10 @@ def main():
                             algorithmic_flops_per_launch=fl, avg_launch_ms=stages["linear"]["ms"],
                             launches_per_step=stages["linear"]["launches"] / sampled,
                             executed_bf16_tflops=6 * fl / t / 1e12, executed_frac_of_bf16_peak=6 * fl / t / BF16_MFMA_PEAK,
+                            skipped_zero_rows=skipping,
                             note="per-launch averages over the grouped launches of a step (3 + 2 + 2 + 1 Linear(H,H) "
-                                 "equivalents); f32 Linear evaluated as six bf16 MFMA cross terms: achieved/peak are the "
+                                 "equivalents, less the rows whose pooled input is all zero when skipped_zero_rows); "
+                                 "f32 Linear evaluated as six bf16 MFMA cross terms: achieved/peak are the "
                                  "algorithmic f32 FLOPs against the dense f32 MFMA peak; executed_* count the "
                                  "bf16 MFMAs actually issued against the dense bf16 peak")
             else:

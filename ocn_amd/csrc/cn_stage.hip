@@ -609,10 +609,10 @@ __device__ __forceinline__ void pool_range(i64 p_begin, i64 p_end, i64 a0, i64 b
                                            const int32_t* __restrict__ wc, const float4* __restrict__ weights,
                                            const float4* __restrict__ h4, i64 rowq, float4 (&acc1)[NV],
                                            float4 (&acc2)[NV]) {
-  // PT positions per lane and round.  (PT = 64/LPE, so that a round always covers 64 positions, was
-  // measured: it does not help the small-batch case — cn_gather_wave_kernel is what does — and costs the
-  // ddi shape 55 %: B = 32 768, H = 64, dense rows served from L2.)
-  constexpr int PT = 1;
+  // Narrow groups (small H) would otherwise pay one dependent load chain (column id -> column weights)
+  // per LPE positions: a lane fetches PT positions per round, so a round always covers 64 of them
+  // (hub rows of the ppa shape: 101 -> 40 us).
+  constexpr int PT = (OCN_WAVE / LPE) < 8 ? (OCN_WAVE / LPE) : 8;
   for (i64 p0 = p_begin; p0 < p_end; p0 += LPE * PT) {
     int32_t k[PT];
     unsigned f[PT];
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
   // hub rows are few and long: more gathers in flight per lane group where the registers allow
-  pool_range<LPE, NV, (LPE * NV <= 32 ? 8 : 4)>(pb, pe, a0, off[e], gl, gbase, colA, flags, wc,
+  pool_range<LPE, NV, (LPE * NV <= (LONG_THREADS == 1024 ? 8 : 32) ? 8 : 4)>(pb, pe, a0, off[e], gl, gbase, colA, flags, wc,
                                                                        weights, h4, rowq, acc1, acc2);
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
@@ -886,6 +886,7 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       float4 t1 = s_part[0][0][gl + v * LPE], t2 = s_part[0][1][gl + v * LPE];
+#pragma unroll 1
       for (int q = 1; q < NG; ++q) {
         const float4 u1 = s_part[q][0][gl + v * LPE], u2 = s_part[q][1][gl + v * LPE];
         t1.x = __fadd_rn(t1.x, u1.x); t1.y = __fadd_rn(t1.y, u1.y); t1.z = __fadd_rn(t1.z, u1.z); t1.w = __fadd_rn(t1.w, u1.w);

@@ -453,13 +453,46 @@ class _CNPredictorBase(nn.Module):
             return _PoolFn.apply(x, st, w)
         st.cls = None
         if (ops.skip_zero_rows and not self.training and not torch.is_grad_enabled() and st.B >= ops.skip_zero_min_batch
-                and st.cnt2 is not None and self._heads_plan(x.shape[1]) is not None):
+                and st.cnt2 is not None and self._heads_plan(x.shape[1]) is not None and self._skip_worthwhile()):
             # class-major rows: candidates without cn1 / cn2 entries end up in contiguous ranges the heads skip
             # (the pooling keeps its own source-sorted, XCD-balanced processing order and only WRITES to the
             # class-major rows: processed class-major, the XCDs holding the heavy classes ran 50 % longer)
             st.cls = ops.class_order(st.cnt1, st.cnt2, st.order, st.ws)
+            self._skip_probe(st.cls[2], st.B)
             return st.gather(w, x, out_row=st.cls[1])
         return st.gather(w, x)
+
+    # Whether skipping pays is a property of the data (a dense graph such as ddi has common neighbours for
+    # every candidate: the re-ordering then only costs).  The class boundaries of a batch are copied to pinned
+    # host memory WITHOUT waiting; whenever a copy has landed by the time a later batch arrives, its skippable
+    # share decides: below ``ops.skip_zero_min_share`` the next ``ops.skip_zero_backoff`` batches run plain.
+    def _skip_worthwhile(self) -> bool:
+        pr = getattr(self, "_skip_state", None)
+        if pr is None:
+            return True
+        if pr["pending"] is not None and pr["pending"].query():
+            r = pr["host"]
+            B = max(int(pr["B"]), 1)
+            cn1, any_, none = int(r[ops.R_CN1][1]), int(r[ops.R_ANY][1]), B - int(r[ops.R_ANY][1])
+            pr["share"] = ((B - cn1) + 2 * none) / (3.0 * B)          # rows skipped in branch a, branch b (cn5) and the mix
+            pr["pending"] = None
+            if pr["share"] < ops.skip_zero_min_share:
+                pr["off"] = ops.skip_zero_backoff
+        if pr["off"] > 0:
+            pr["off"] -= 1
+            return False
+        return True
+
+    def _skip_probe(self, ranges: Tensor, B: int) -> None:
+        pr = getattr(self, "_skip_state", None)
+        if pr is None:
+            pr = self._skip_state = dict(host=torch.empty((ops.CLASS_RANGES, 2), dtype=torch.int64).pin_memory(),
+                                         pending=None, B=0, off=0, share=1.0)
+        pr["calls"] = pr.get("calls", 0) + 1
+        if pr["pending"] is None and pr["calls"] % 8 == 1:               # a 112-byte copy every 8th batch
+            pr["host"].copy_(ranges, non_blocking=True)
+            pr["B"] = B
+            pr["pending"] = torch.cuda.current_stream(ranges.device).record_event()
 
     def _heads_plan(self, H: int):
         """Parsed stages of the four heads when the zero-row-skipping evaluation applies (3-layer pooled

@@ -20,6 +20,8 @@ stage_timer = None               # optional object with .mark(name): bench.py re
 LN_WIDTHS = (16, 32, 64, 128, 256, 512)   # row widths of the lane-group kernels (LayerNorm, pooling backward)
 a2_bitmap_max_bytes = 16 << 30   # keep A·B also as dense bit rows when n_rows * n_cols / 8 fits this budget
 skip_zero_rows = True            # heads: skip the layers whose pooled input row is all zero (class-major rows)
+skip_zero_min_share = 0.15       # ... and when fewer than this share of the head rows could be skipped (probed asynchronously)
+skip_zero_backoff = 32           # batches evaluated plainly before the share is probed again
 skip_zero_min_batch = 4096       # below this the extra small launches cost more than the skipped rows save
 walk_two_sided = True            # walk route: sweep each candidate from its cheaper endpoint (needs nds of the adjacency)
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
