@@ -243,6 +243,7 @@ def class_order(cnt1: Tensor, cnt2: Optional[Tensor], order: Optional[Tensor], w
     ws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, dev)
     check(_lib.lib().ocn_class_order(ptr(cnt1), ptr(cnt2), ptr(order), B, ptr(order2), ptr(inv), ptr(ranges),
                                      ptr(prefix), ptr(ws), stream_ptr()), "ocn_class_order")
+    _mark("cn_class")
     return order2, inv, ranges
 
 
