@@ -57,6 +57,19 @@ APPENDIX_C = {
             "ncn2": [0.5, -5.727272, 1.0, 3.363636, 0.5, 3.363636],
         },
         "q2_single_edge_batch": {"batch": [[0, 1]], "S1_col2": 1, "cn5_inv1_col2": 0.0},
+        # Hand-derived from NeighborOverlap_large_ppa.py:147-173: cn2[e,k] = |N(k) ∩ N(j_e)| for k in N(i_e),
+        # zeros dropped.  e0 = (0,1): N(1)∩N(1) = {0,2} -> 2, N(2)∩N(1) = {0} -> 1; e1 = (1,3): N(0)∩N(3) = {2}
+        # -> 1, N(2)∩N(3) = {} dropped; e2 = (0,3): N(1)∩N(3) = {2} -> 1, N(2)∩N(3) = {} dropped.
+        "walk_route": {"cn2_rows": [[1, 2], [0], [1]], "cn2_values": [[2.0, 1.0], [1.0], [1.0]],
+                       "walk_colsum": [1.0, 3.0, 1.0, 0.0]},
+        # model.py:3114-3126, 3186-3216 with x[k] = one-hot(k): S1 = [0,0,3,0] so ncn1 = 1/3 on column 2 of every
+        # row; cn2 is pooled raw (the walk counts above)
+        "cn7_walk": {"xcn1": [[0, 0, 0.33333334, 0]] * 3, "xcn2": [[0, 2.0, 1.0, 0], [1.0, 0, 0, 0], [0, 1.0, 0, 0]]},
+        # model.py:2846-2933 at innerprod = 0: N^3(1) = {0,1,2,3}, N^3(3) = N(0) ∪ N(1) ∪ N(3) = {0,1,2};
+        # cn3 = N(i) ∩ N^3(j); S3 = its column counts [1,2,3,0]; ncn3 = 1/S3
+        "cn6_innerprod_0": {"a3_rows": {"1": [0, 1, 2, 3], "3": [0, 1, 2]}, "cn3_rows": [[1, 2], [0, 2], [1, 2]],
+                            "S3": [1.0, 2.0, 3.0, 1.0],
+                            "xcn3": [[0, 0.5, 0.33333334, 0], [1.0, 0, 0.33333334, 0], [0, 0.5, 0.33333334, 0]]},
     },
 }
 

@@ -58,6 +58,33 @@ def test_path_graph_known_answers(appc):
     assert aux["inv1"][2].item() == pytest.approx(2.74) and torch.allclose(xc1[0], 2.74 * x[2])
 
 
+def test_path_graph_walk_route_cn7_and_cn6_known_answers(appc):
+    """Hand-derived answers (tests/golden/make_golden.py) for the pygho route, cn7 on it, and cn6."""
+    g = appc["path_graph"]
+    adj = O.to_symmetric(O.from_edge_index(torch.tensor(g["undirected_edges"]).t(), g["n"]))
+    e = torch.tensor(g["batch"]).t().contiguous()
+    c1, c2 = O.get_cn1_cn2(adj, e)
+    w = g["walk_route"]
+    assert [c1.col[c1.row == r].tolist() for r in range(3)] == g["cn1_rows"]
+    assert [c2.col[c2.row == r].tolist() for r in range(3)] == w["cn2_rows"]
+    assert [c2.val[c2.row == r].tolist() for r in range(3)] == w["cn2_values"]
+    assert O.col_sum(c2).tolist() == w["walk_colsum"]
+    eye = torch.eye(4)
+    x1, x2, _ = O.cn7_pool(eye, c1, c2, 1.0)
+    assert torch.allclose(x1, torch.tensor(g["cn7_walk"]["xcn1"]), rtol=1e-6, atol=0)
+    assert torch.equal(x2, torch.tensor(g["cn7_walk"]["xcn2"]))
+    a2 = O.adj2_sparse(adj)
+    a3 = O.adj3_sparse(adj, a2)
+    k6 = g["cn6_innerprod_0"]
+    for r_, cols in k6["a3_rows"].items():
+        assert a3.col[a3.row == int(r_)].tolist() == cols
+    cn3 = O.adjoverlap(adj, a3, e)
+    assert [cn3.col[cn3.row == r].tolist() for r in range(3)] == k6["cn3_rows"]
+    _, _, x3, aux = O.cn6_pool(eye, O.adjoverlap(adj, adj, e), O.adjoverlap(adj, a2, e), cn3, torch.tensor([0.0]))
+    assert aux["S3"].tolist() == k6["S3"]
+    assert torch.allclose(x3, torch.tensor(k6["xcn3"]), rtol=1e-6, atol=0)
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_oracle_vs_naive_model(seed):
     n, B, H = 150 + 40 * seed, 120, 12

@@ -234,6 +234,24 @@ def test_appendix_c_on_gpu(hiplib):
     assert w[2, 0].item() == 0.0
     g1, _, _ = st.gather(w, eye)
     assert g1.abs().max().item() == 0.0
+    # pygho route, cn7 on it, cn6 (hand-derived, tests/golden/make_golden.py)
+    from ocn_amd.utils import CNState3
+    wk = g["walk_route"]
+    st = CNState(adj, None, None, e, walk=True)
+    assert st.cnt1.cpu().tolist() == g["cn1_counts"] and st.cnt2.cpu().tolist() == [len(r_) for r_ in wk["cn2_rows"]]
+    assert st.hist_counts().cpu()[:, 3].tolist() == wk["walk_colsum"]
+    x1, x2, _ = st.gather(st.weights_cn7(1.0), eye)
+    assert torch.allclose(x1[:, :4].cpu(), torch.tensor(g["cn7_walk"]["xcn1"]), rtol=1e-6, atol=0)
+    assert torch.equal(x2[:, :4].cpu(), torch.tensor(g["cn7_walk"]["xcn2"]))
+    k6 = g["cn6_innerprod_0"]
+    adj3 = SparseTensor.from_torch_sparse_coo_tensor(adj2.to_torch_sparse_coo_tensor() @ adj.to_torch_sparse_coo_tensor(), False)
+    r3, c3, _ = adj3.coo()
+    for r_, cols in k6["a3_rows"].items():
+        assert c3[r3 == int(r_)].cpu().tolist() == cols
+    st3 = CNState3(adj, adj2, adj3, e)
+    assert st3.cnt3.cpu().tolist() == [len(r_) for r_ in k6["cn3_rows"]]
+    x3 = st3.gather(*st3.weights(torch.zeros(1, device=DEV)), eye)[2]
+    assert torch.allclose(x3[:, :4].cpu(), torch.tensor(k6["xcn3"]), rtol=1e-6, atol=0)
 
 
 def test_oracle_vectors_regression(hiplib):
