@@ -603,7 +603,10 @@ __device__ __forceinline__ void entry_weights(unsigned f, const float4& w, float
 // Pool the flagged neighbours at positions [p_begin, p_end) of the source row into acc1 / acc2, in
 // ascending position (= column) order.  LPE lanes cooperate; each lane owns NV float4 of the
 // H = LPE*NV*4 features; four embedding rows are in flight per group.
-template <int LPE, int NV, int UNR = 4>
+#ifndef OCN_X_GATHER_UNR
+#define OCN_X_GATHER_UNR 4
+#endif
+template <int LPE, int NV, int UNR = OCN_X_GATHER_UNR>
 __device__ __forceinline__ void pool_range(i64 p_begin, i64 p_end, i64 a0, i64 base, int gl, int gbase,
                                            const int32_t* __restrict__ colA, const uint8_t* __restrict__ flags,
                                            const int32_t* __restrict__ wc, const float4* __restrict__ weights,
