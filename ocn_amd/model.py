@@ -525,16 +525,23 @@ class _CNPredictorBase(nn.Module):
                 self.innerprod += beta * ip
         return self.innerprod
 
+    def _drop_caches(self) -> None:
+        self._coef_key = self._mixw_key = self._zc_key = self._plan_key = None
+        self._zc_params = None
+        for p in self.parameters():
+            ops._panels.pop(id(p), None)
+
+    def _apply(self, fn, *a, **kw):
+        """.to() / .cuda() / .float(): parameters are re-created, so every cached derivative goes."""
+        out = super()._apply(fn, *a, **kw)
+        self._drop_caches()
+        return out
+
     def train(self, mode: bool = True):
         """Mode switches (the drivers call .train() / .eval() around every pass) also drop the cached
         eval-path constants, so edits that bypass the version counters (``param.data``) cannot go stale
         across a training pass."""
-        self._coef_key = None
-        self._mixw_key = None
-        self._zc_key = None
-        self._plan_key = None
-        for p in self.parameters():
-            ops._panels.pop(id(p), None)
+        self._drop_caches()
         return super().train(mode)
 
     def _mix_coef(self) -> Tensor:
@@ -565,8 +572,11 @@ class _CNPredictorBase(nn.Module):
         layer of xcn1lin (xcn2lin) on a zero row, and the mix layer of the two — computed by the SAME
         kernels on a one-row zero input, so a skipped row gets bit for bit what it would have computed.
         Cached on the parameter versions."""
-        key = tuple((p.data_ptr(), p._version) for seq in (self.xcn1lin, self.xcn2lin) for p in seq.parameters()) \
-            + (self._mix_coef().data_ptr(), self._coef_key)
+        plist = getattr(self, "_zc_params", None)
+        if plist is None:             # (walking the module tree every batch cost 60 us of host time)
+            plist = self._zc_params = [p for seq in (self.xcn1lin, self.xcn2lin) for p in seq.parameters()]
+        self._mix_coef()
+        key = (tuple(p._version for p in plist), self._coef_key)
         if getattr(self, "_zc_key", None) != key:
             z1 = torch.zeros(1, H, device=dev)
             t = torch.empty(2, 1, H, device=dev)
