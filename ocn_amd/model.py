@@ -292,7 +292,14 @@ class _Encoder(nn.Module):
         jkx = []
         for i, conv in enumerate(self.convs):
             a = self.adjdrop(adj_t) if self._use_adjdrop else adj_t
-            x1 = self.lins[i](conv(x, a))
+            x1 = conv(x, a)
+            if (isinstance(self.lins[i], nn.Sequential) and not self.training and not torch.is_grad_enabled()
+                    and x1.is_cuda and x1.dim() == 2 and x1.dtype == torch.float32 and x1.is_contiguous()):
+                # eval: LayerNorm + ReLU of a layer in one HIP pass (torch's LayerNorm kernel runs at 0.26 TB/s on
+                # the 32-wide rows of the citation2 encoder: 2.9 ms per layer against 0.2 ms)
+                x1 = _seq_eval(self.lins[i], x1)
+            else:
+                x1 = self.lins[i](x1)
             x = x1 + x if (self.res and x1.shape[-1] == x.shape[-1]) else x1
             if self.jk:
                 jkx.append(x)
