@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as a captured HIP graph (pipeline.GraphedScorer; one GPU, no stage events: "
+                         "the roofline objects are then null); small-batch configurations only (cora, ppa, citation2)")
     ap.add_argument("--prewarm", type=int, default=64, help="untimed runtime pre-warm steps before --warmup")
     ap.add_argument("--run-ahead", type=int, default=6, help="steps the host may enqueue ahead of the GPU")
     ap.add_argument("--timer-every", type=int, default=8, help="record stage events on every n-th timed step")
@@ -266,6 +269,18 @@ def main():
     out = step()                                   # validated once (bounds check + flag capacity)
     torch.cuda.synchronize()
     ops.validate_indices = False                   # same ids every step: no per-step host sync
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph is a single-GPU option")
+        from ocn_amd.pipeline import GraphedScorer
+        scorer = GraphedScorer(pred, h, adj, wl.get("adj2"), mine.shape[1], wl["args"],
+                               route="walk" if cfg["route"] == "walk" else "pattern")
+        eager_step = step
+
+        def step():
+            return scorer(mine)
+        assert torch.equal(step(), eager_step())
+        args.no_stage_timers = True
     # Runtime pre-warm (untimed, before the W warm-up steps): the HIP runtime grows its internal
     # command/signal pools in ~35 ms host stalls during the first ~1000 launches of a process; a short
     # --warmup would otherwise put one of them inside the timed region.

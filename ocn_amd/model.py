@@ -496,6 +496,8 @@ class _CNPredictorBase(nn.Module):
             pr = self._skip_state = dict(host=torch.empty((ops.CLASS_RANGES, 2), dtype=torch.int64).pin_memory(),
                                          pending=None, B=0, off=0, share=1.0)
         pr["calls"] = pr.get("calls", 0) + 1
+        if torch.cuda.is_current_stream_capturing():                     # (a graph replays whatever was decided at capture)
+            return
         if pr["pending"] is None and pr["calls"] % 8 == 1:               # a 112-byte copy every 8th batch
             pr["host"].copy_(ranges, non_blocking=True)
             pr["B"] = B

@@ -220,3 +220,34 @@ def test_citation2_mrr_layout_matches_the_oracle_loop(hiplib):
     want = ev.eval({"y_pred_pos": ref_pos, "y_pred_neg": ref_neg})["mrr_list"].mean().item()
     got = score_mrr_split(pred, h.to(DEV), adj, source.to(DEV), target.to(DEV), target_neg.to(DEV), bs, args, evaluator=ev)
     assert got == pytest.approx(want, abs=1e-6)
+
+
+@pytest.mark.parametrize("name,route", [("cn5", "pattern"), ("cn7", "walk")])
+def test_graphed_scorer_replays_what_eager_computes(hiplib, name, route):
+    """pipeline.GraphedScorer: one batch as a captured HIP graph; replays on new candidate ids are bitwise
+    what the eager call returns."""
+    import ocn_amd.model as M
+    from ocn_amd.pipeline import GraphedScorer
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import adjoverlap, get_cn1_cn2
+    n, shape, oadj, adj = _graph("cora", 1.0, seed=2)
+    sp = adj.to_torch_sparse_coo_tensor()
+    adj2 = SparseTensor.from_torch_sparse_coo_tensor(sp @ sp, False)
+    H, B = 64, 1152
+    torch.manual_seed(5)
+    h = torch.randn(n, H, device=DEV)
+    pred = M.predictor_dict[name](H, H, 1, 3, 0.0, 0.0, True, use_xlin=True, tailact=True).to(DEV).eval()
+    args = SimpleNamespace(sum=1.0)
+    scorer = GraphedScorer(pred, h, adj, adj2, B, args, route=route)
+    for seed in (1, 2, 3):
+        e = sample_edges(oadj.row, oadj.col, n, B, seed=seed).to(DEV)
+        got = scorer(e, check=True).clone()
+        with torch.no_grad():
+            c1, c2 = get_cn1_cn2(adj, e) if route == "walk" else (adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e))
+            want = pred(h, adj, c1, c2, e, args)
+        assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        scorer(e[:, :100])
+    with pytest.raises(IndexError):
+        bad = e.clone(); bad[0, 0] = n + 5
+        scorer(bad, check=True)
