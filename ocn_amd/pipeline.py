@@ -1,93 +1,46 @@
-"""Batched scoring with the memory-bound CN stage and the MFMA-bound MLP heads on two HIP streams.
+"""Batched scoring loops of the drivers' ``test()`` functions with the scores kept on the device.
 
 ``score_edges`` computes exactly what the reference's ``test()`` computes with
 
     torch.cat([predictor(h, adj, adjoverlap(adj, adj, e[perm].t()), adjoverlap(adj, adj2, e[perm].t()),
                          e[perm].t(), args).squeeze().cpu() for perm in PermIterator(dev, n, bs, False)])
 
-(NeighborOverlap_large.py:121-159) — same batch composition, so the same batch-coupled
-normalisation — but keeps the scores on the device and lets batch t+1's intersection / pooling
-kernels (HBM- and L2-bound, no LDS, < 64 VGPRs) run beside batch t's Linear layers (fp32 MFMA
-GEMMs) instead of behind them.  One D2H copy at the end replaces one blocking ``.cpu()`` per batch.
+(NeighborOverlap_large.py:121-159) — same batch composition, so the same batch-coupled normalisation —
+with one D2H copy at the end instead of one blocking ``.cpu()`` per batch.  (An earlier version ran the
+CN stage of batch t+1 on a second stream beside the MLP heads of batch t: +4 % only, the MFMA kernels
+leave no registers for a co-resident wave — DESIGN.md §4; the single-stream loop below, which gets the
+predictor's scratch reuse and zero-row skipping, is faster.)
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import Optional
 
 import torch
 from torch import Tensor
 
 from . import ops
-from .utils import CNState, PermIterator
-
-
-class TwoStreamScorer:
-    """Reusable pair of side streams for one predictor on one device."""
-
-    def __init__(self, predictor, device=None):
-        self.pred = predictor
-        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        self.dev = dev
-        self.cn_stream = torch.cuda.Stream(device=dev)
-        self.mlp_stream = torch.cuda.Stream(device=dev)
-
-    def begin(self) -> None:
-        """Make both side streams wait for whatever produced the inputs on the current stream."""
-        cur = torch.cuda.current_stream(self.dev)
-        self.cn_stream.wait_stream(cur)
-        self.mlp_stream.wait_stream(cur)
-
-    def submit(self, h: Tensor, adj, adj2, edges: Tensor, args=None) -> Tensor:
-        """Enqueue one candidate batch; returns the [B,1] score tensor (valid after ``end()`` or a
-        wait on ``mlp_stream``)."""
-        pred = self.pred
-        is_cn7 = hasattr(args, "sum") and type(pred).__name__ == "CNLinkPredictorbaselearn"
-        # the batch slice was produced on the caller's stream just now
-        cur = torch.cuda.current_stream(self.dev)
-        self.cn_stream.wait_event(cur.record_event())
-        edges.record_stream(self.cn_stream)
-        with torch.cuda.stream(self.cn_stream):
-            st = pred._exchange(CNState(adj, adj, adj2, edges))
-            w = st.weights_cn7(float(args.sum)) if is_cn7 else st.weights_cn5(pred.innerprod)
-            xcn1, xcn2, xij = st.gather(w, h)
-            ready = self.cn_stream.record_event()
-        for t in (xcn1, xcn2, xij):
-            t.record_stream(self.mlp_stream)
-        with torch.cuda.stream(self.mlp_stream):
-            self.mlp_stream.wait_event(ready)
-            ops._mark("begin")
-            out = pred._heads(h, xcn1, xcn2, xij)
-            ops._mark("mlp")
-        return out
-
-    def end(self, outs: List[Tensor]) -> None:
-        cur = torch.cuda.current_stream(self.dev)
-        cur.wait_stream(self.mlp_stream)
-        cur.wait_stream(self.cn_stream)
-        for o in outs:
-            o.record_stream(cur)
+from .utils import PermIterator
 
 
 @torch.no_grad()
 def score_edges(predictor, h: Tensor, adj, adj2, edges: Tensor, batch_size: int, args=None,
-                scorer: Optional[TwoStreamScorer] = None, run_ahead: int = 6) -> Tensor:
+                run_ahead: int = 6) -> Tensor:
     """Scores for ``edges`` [n, 2] (the layout of ``split_edge[...]['edge']``), batched like
     ``PermIterator(.., training=False)``; returns a [n] fp32 tensor on the device.  The host stays at
     most ``run_ahead`` batches ahead of the GPU: an unbounded backlog makes the HIP runtime block the
-    host until the queue has drained completely, and it bounds the live scratch."""
+    host until the queue has drained completely."""
+    from .utils import adjoverlap
     if predictor.training:
         raise RuntimeError("score_edges is the eval path; call predictor.eval() first")
-    scorer = scorer or TwoStreamScorer(predictor, h.device)
     h = h.contiguous()
-    scorer.begin()
     outs, done = [], []
     for perm in PermIterator(edges.device, edges.shape[0], batch_size, training=False):
         if len(done) >= max(run_ahead, 1):
             done.pop(0).synchronize()
-        outs.append(scorer.submit(h, adj, adj2, edges[perm].t().contiguous(), args))
-        done.append(scorer.mlp_stream.record_event())
-    scorer.end(outs)
-    return torch.cat(outs, dim=0).squeeze(-1) if outs else h.new_zeros(0)
+        e = edges[perm].t().contiguous()
+        outs.append(predictor(h, adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e), e, args).reshape(-1))
+        done.append(torch.cuda.current_stream(h.device).record_event())
+    return torch.cat(outs, dim=0) if outs else h.new_zeros(0)
 
 
 @torch.no_grad()
