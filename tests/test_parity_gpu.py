@@ -832,3 +832,22 @@ def test_zero_row_skipping_is_bitwise_neutral(hiplib, name, H, tailact, two):
         finally:
             ops.skip_zero_rows = True
     assert outs[0].shape == (B, 1) and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("name,fin,H", [("cn5", 64, 128), ("cn7", 48, 32), ("cn5", 32, 40)])
+def test_predictor_with_input_width_different_from_hidden(case, name, fin, H):
+    """in_channels != hidden_channels (an encoder narrower than the predictor), and a hidden width none of
+    the MFMA kernels take: the heads then walk branch by branch / through the torch modules — same scores."""
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    torch.manual_seed(21)
+    x = torch.randn(case.n, fin)
+    pred = predictor_dict[name](fin, H, 1, 3, 0.1, 0.0, True, use_xlin=True, tailact=True).eval()
+    sd = {k: v.detach().clone() for k, v in pred.state_dict().items()}
+    args = SimpleNamespace(sum=0.5)
+    ref = (O.cn5_forward(sd, x, case.ocn1, case.ocn2, case.e, True, True) if name == "cn5"
+           else O.cn7_forward(sd, x, case.ocn1, case.ocn2, case.e, args.sum, True, True))
+    e = case.e.to(DEV)
+    with torch.no_grad():
+        out = pred.to(DEV)(x.to(DEV), case.adj, adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e), e, args)
+    assert close(out, ref), (out.cpu() - ref).abs().max()
