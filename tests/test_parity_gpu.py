@@ -851,3 +851,25 @@ def test_predictor_with_input_width_different_from_hidden(case, name, fin, H):
     with torch.no_grad():
         out = pred.to(DEV)(x.to(DEV), case.adj, adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e), e, args)
     assert close(out, ref), (out.cpu() - ref).abs().max()
+
+
+def test_walk_route_on_a_dense_graph(hiplib):
+    """Half of all pairs connected: nearly every swept element is a hit, so the LDS hit queue overflows and
+    the in-place resolution path of the sweep runs; counts and values still equal the oracle's."""
+    from ocn_amd.utils import CNState
+    n, B = 400, 700
+    g = torch.Generator().manual_seed(12)
+    up = torch.triu(torch.rand(n, n, generator=g) < 0.5, diagonal=1)
+    ei = up.nonzero().t().contiguous()
+    oadj = O.to_symmetric(O.from_edge_index(ei, n))
+    adj = to_product(oadj, DEV)
+    e = torch.randint(0, n, (2, B), generator=g)
+    oc1, oc2 = O.get_cn1_cn2(oadj, e)
+    for nds in (None, adj.neighbor_degree_sum()):
+        flags, wc, hc, c1, c2 = _walk_raw(adj, e.to(DEV), nds)
+        assert c1.tolist() == torch.bincount(oc1.row, minlength=B).tolist()
+        assert c2.tolist() == torch.bincount(oc2.row, minlength=B).tolist()
+        assert hc[:, 3].tolist() == torch.zeros(n, dtype=torch.long).index_add_(0, oc2.col, oc2.val.long()).tolist()
+    st = CNState(adj, None, None, e.to(DEV), walk=True)
+    m2 = st.materialize(2)
+    assert spm_equal(m2, oc2) and m2.storage.value().cpu().tolist() == oc2.val.tolist()
