@@ -7,9 +7,14 @@ A step = one candidate batch through the hot path exactly as ``test()`` runs it
 (NeighborOverlap_large.py:121-159): the CN builder (adjoverlap(A, A, e) + adjoverlap(A, A², e), or
 get_cn1_cn2(A, e) on the pygho route), then the predictor forward (intersection -> column weights ->
 pooling -> MLP heads), with the encoder output h and A² computed once per graph outside the timed
-region and everything resident in HBM.
+region and everything resident in HBM.  The predictor is built the way the reference drivers build it
+(NeighborOverlap_large.py:272-276,297-298: for cn5 / cn7 only ``cndeg`` is forwarded, so --use_xlin /
+--tailact / --beta of the README commands are dead flags and the head is 9 Linear(H,H) + Linear(H,1)).
+The timed steps rotate over ``--batches`` (8) distinct seeded candidate batches, whose ids were
+bounds-checked once before the timed region (what ``pipeline.score_edges`` does for a whole split);
+``value_validate_per_batch`` is the same loop with the per-batch check (one host sync per batch) left on.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 128 --warmup 8
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
     python bench.py --config citation2          # other BASELINE configs: citation2 | ppa | ddi | cora
@@ -19,10 +24,12 @@ a global batch of N x batch (weak scaling); per step one RCCL all-reduce of the 
 histograms and one all-gather of the scores (ocn_amd/dist.py).
 """
 import argparse
+import glob
 import json
 import os
 import sys
 import time
+from functools import partial
 from types import SimpleNamespace
 
 import torch
@@ -34,15 +41,35 @@ HBM_PEAK = 8.0e12       # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 
 F32_MFMA_PEAK = 157.3e12    # FLOP/s, dense f32-in/f32-acc MFMA (same guide, chip-level table)
 BF16_MFMA_PEAK = 2.5e15     # FLOP/s, dense bf16 MFMA
 
-# the reference's README commands (README.md:27,42,47,92,98): encoder class, conv, layers, hiddim,
-# predictor, CN route, batch, ids-as-features, args.sum
+# the reference's README commands (README.md:27,42,47,92,98): encoder class, conv, layers, hiddim, predictor
+# (BASELINE.json's), CN route, batch, ids-as-features, args.sum, and the flags each command sets: --ln (encoder
+# LayerNorm), --lnnn (predictor LayerNorm), --res, --jk, --nnlayers, --predp, --preedp
 CONFIGS = {
-    "collab":    dict(enc="GCN",  conv="gin",     layers=1, H=256, pred="cn5", route="adj2",  batch=65536, ids=False, sum=0.0, res=False),
-    "cora":      dict(enc="GCN",  conv="puregcn", layers=1, H=256, pred="cn5", route="adj2",  batch=1152,  ids=False, sum=0.0, res=False),
-    "ppa":       dict(enc="GCN2", conv="gcn",     layers=1, H=64,  pred="cn5", route="walk",  batch=2048,  ids=True,  sum=0.0, res=False),
-    "citation2": dict(enc="GCN3", conv="gcn",     layers=5, H=32,  pred="cn7", route="walk",  batch=2048,  ids=False, sum=1.0, res=True),
-    "ddi":       dict(enc="GCN",  conv="puregcn", layers=3, H=64,  pred="cn7", route="block", batch=32768, ids=True,  sum=2.74, res=True),
+    "collab":    dict(enc="GCN",  conv="gin",     layers=1, H=256, pred="cn5", route="adj2",  batch=65536, ids=False, sum=1.0,
+                      ln=True,  lnnn=True,  res=False, jk=True,  nnlayers=3, predp=0.05, preedp=0.4),
+    "cora":      dict(enc="GCN",  conv="puregcn", layers=1, H=256, pred="cn5", route="adj2",  batch=1152,  ids=False, sum=0.0,
+                      ln=True,  lnnn=True,  res=False, jk=True,  nnlayers=3, predp=0.05, preedp=0.4),
+    "ppa":       dict(enc="GCN2", conv="gcn",     layers=1, H=64,  pred="cn5", route="walk",  batch=2048,  ids=True,  sum=0.0,
+                      ln=True,  lnnn=True,  res=False, jk=True,  nnlayers=3, predp=0.0,  preedp=0.0),
+    "citation2": dict(enc="GCN3", conv="gcn",     layers=5, H=32,  pred="cn7", route="walk",  batch=2048,  ids=False, sum=1.0,
+                      ln=True,  lnnn=False, res=True,  jk=True,  nnlayers=3, predp=0.10, preedp=0.12),
+    "ddi":       dict(enc="GCN",  conv="puregcn", layers=3, H=64,  pred="cn7", route="block", batch=32768, ids=True,  sum=2.74,
+                      ln=False, lnnn=True,  res=True,  jk=False, nnlayers=3, predp=0.10, preedp=0.13),
 }
+
+
+def head_layout(pred) -> str:
+    """'xcn1lin 3 + xcn2lin 3 + xijlin 2 + lin 1 Linear(H,H) + Linear(H,1)' read off the module."""
+    import torch.nn as nn
+    parts, tot = [], 0
+    for name in ("xcn1lin", "xcn2lin", "xijlin", "lin"):
+        seq = getattr(pred, name)
+        hh = sum(1 for m in seq if isinstance(m, nn.Linear) and m.out_features == m.in_features)
+        tail = sum(1 for m in seq if isinstance(m, nn.Linear) and m.out_features == 1)
+        lns = sum(1 for m in seq if isinstance(m, nn.LayerNorm))
+        tot += hh
+        parts.append(f"{name}: {hh} Linear(H,H)" + (f" + Linear(H,1)" if tail else "") + (f", {lns} LayerNorm" if lns else ""))
+    return f"{tot} Linear(H,H) + dot per edge [" + "; ".join(parts) + "]"
 
 
 class StageTimer:
@@ -75,6 +102,15 @@ class StageTimer:
         return {k: (sum(v) / len(v), len(v)) for k, v in tot.items()}
 
 
+def make_predictor(cfg, dev):
+    """predfn = partial(predictor_dict[name], cndeg=args.cndeg); predfn(hiddim, hiddim, 1, nnlayers, predp,
+    preedp, lnnn) — NeighborOverlap_large.py:272-276,297-298 (same in the ppa / citation2 drivers)."""
+    import ocn_amd.model as M
+    H = cfg["H"]
+    predfn = partial(M.predictor_dict[cfg["pred"]], cndeg=-1)
+    return predfn(H, H, 1, cfg["nnlayers"], cfg["predp"], cfg["preedp"], cfg["lnnn"]).to(dev).eval()
+
+
 def build_workload(args, dev, rank, world):
     import ocn_amd.model as M
     from ocn_amd.sparse import SparseTensor
@@ -98,9 +134,11 @@ def build_workload(args, dev, rank, world):
     else:
         fin, max_x = (shape["feat"] or H), -1
         x = torch.randn(n, fin, device=dev)
-    enc = getattr(M, cfg["enc"])(fin, H, H, cfg["layers"], 0.05, True, cfg["res"], max_x, cfg["conv"], True, 0.0,
+    enc = getattr(M, cfg["enc"])(fin, H, H, cfg["layers"], 0.05, cfg["ln"], cfg["res"], max_x, cfg["conv"], cfg["jk"], 0.0,
                                  xdropout=0.7, taildropout=0.3).to(dev).eval()
-    pred = M.predictor_dict[cfg["pred"]](H, H, 1, 3, 0.05, 0.4, True, use_xlin=True, tailact=True).to(dev).eval()
+    pred = make_predictor(cfg, dev)
+    if args.innerprod:
+        pred.innerprod.fill_(args.innerprod)           # a trained checkpoint's buffer (order-exact S2 path of cn5)
     with torch.no_grad():
         h = enc(x, adj)
         torch.cuda.synchronize()
@@ -120,8 +158,9 @@ def build_workload(args, dev, rank, world):
         torch.cuda.synchronize()
         t_a2 = time.time() - t0
     r, c, _ = adj.coo()
-    # one global batch of world x B edges, seeded; rank r owns slice r
-    edges = sample_edges(r.cpu(), c.cpu(), n, cfg["batch"] * world, seed=1).to(dev)
+    rc, cc = r.cpu(), c.cpu()
+    # `batches` global batches of world x B edges each, seeded 1, 2, ...; rank r owns slice r of each
+    edges = [sample_edges(rc, cc, n, cfg["batch"] * world, seed=1 + b).to(dev) for b in range(max(args.batches, 1))]
     return dict(cfg=cfg, n=n, adj=adj, adj2=adj2, h=h.contiguous(), pred=pred, edges=edges, enc_s=t_enc, a2_s=t_a2,
                 graph_s=t_graph, nnz=adj.nnz(), nnz2=adj2.nnz() if adj2 is not None else None,
                 max_deg=adj.max_rowcount(), args=SimpleNamespace(sum=cfg["sum"]))
@@ -134,105 +173,153 @@ def cn_handles(wl, e):
     return adjoverlap(wl["adj"], wl["adj"], e), adjoverlap(wl["adj"], wl["adj2"], e)
 
 
-def algorithmic_bytes(wl, mine, cnt1, cnt2, H):
-    """bytes(e) = 4(d_i+d_j) + 4 d2_j + 4H(c1+c2) + 8H + 28, split by the kernel that
-    has to move them.  On the walk route there is no A² row; the builder reads the rows of the
-    neighbours of i instead: 4(d_i + d_j + sum_{k in N(i)} d_k)."""
+def batch_bytes(wl, mine, H):
+    """Byte counts of one candidate batch, per kernel.
+
+    ``formula``: SURVEY.md §8(d), bytes(e) = 4(d_i+d_j) + 4 d2_j + 4H(c1+c2) + 8H + 28 — one embedding row per CN
+    entry, the whole A² row of j.  ``compulsory``: what a kernel with an ideal cache has to move for this batch —
+    every DISTINCT embedding row / weight row once, the CSR rows it walks once, its outputs once; on the walk
+    route the rows of the cheaper endpoint's neighbours (what the two-sided sweep enumerates), not Σ_{k∈N(i)} d_k.
+    ``achieved`` in the roofline objects is compulsory bytes / time (never above the HBM peak by construction of
+    an ideal-cache count); the formula figure is printed beside it."""
+    from ocn_amd.utils import CNState
     adj = wl["adj"]
     rp = adj._rowptr
     deg = rp[1:] - rp[:-1]
-    di = deg[mine[0]].sum().item()
-    dj = deg[mine[1]].sum().item()
+    src, dst = mine[0], mine[1]
     B = mine.shape[1]
-    if wl["adj2"] is not None:
-        rp2 = wl["adj2"]._rowptr
-        second = (rp2[mine[1] + 1] - rp2[mine[1]]).sum().item()
+    walk = wl["cfg"]["route"] == "walk"
+    st = CNState(adj, None, None, mine, walk=True) if walk else CNState(adj, adj, wl["adj2"], mine)
+    cnt1, cnt2 = st.cnt1, st.cnt2
+    di, dj = deg[src], deg[dst]
+    sdi, sdj = int(di.sum()), int(dj.sum())
+    c12 = int(cnt1.sum()) + int(cnt2.sum())
+    hc = st.hist_counts()
+    touched_cols = int((hc[:, 2] > 0).sum())                       # distinct columns with a union entry
+    rows_h = torch.zeros(wl["n"], dtype=torch.bool, device=mine.device)
+    rows_h[hc[:, 2] > 0] = True
+    rows_h[src] = True
+    rows_h[dst] = True
+    distinct_h = int(rows_h.sum())
+    has_any = (cnt1 > 0) | (cnt2 > 0)
+    pooled_rows_walked = int(di[has_any].sum())                    # rows without an entry are not walked
+    if walk:
+        nds = adj.neighbor_degree_sum()
+        ndi, ndj = nds[src], nds[dst]
+        rev = (dj > 0) & (di > 0) & ((2 * ndj + di * ((dj + 15) // 16) + 2 * di) < ndi)     # csrc/common.h walk_reverse
+        swept = int(torch.where(rev, ndj, ndi).sum())
+        second_formula = int(ndi.sum())
+        flags_formula = 4 * (sdi + sdj) + 4 * second_formula + 24 * B
+        flags_comp = 4 * (sdi + sdj) + 4 * swept + 5 * sdi + 24 * B          # + flag byte and walk count per position
     else:
-        r, c, _ = adj.coo()
-        nbr_deg = torch.zeros(wl["n"], dtype=torch.int64, device=r.device).index_add_(0, r, deg[c])
-        second = nbr_deg[mine[0]].sum().item()
-    c12 = int(cnt1.sum().item()) + int(cnt2.sum().item())
-    flags = 4 * (di + dj) + 4 * second + 24 * B       # CSR rows of i, j, A² row of j (or rows of N(i)), ids, counts
-    gather = 4 * H * c12 + 8 * H * B + 4 * B          # one embedding row per CN entry, x_i, x_j, score
-    return dict(cn_flags=flags, cn_gather=gather, total=flags + gather,
-                mean_di=di / B, mean_dj=dj / B, mean_second=second / B, mean_c1=cnt1.float().mean().item(),
-                mean_c2=cnt2.float().mean().item())
+        rp2 = wl["adj2"]._rowptr
+        second_formula = int((rp2[dst + 1] - rp2[dst]).sum())
+        flags_formula = 4 * (sdi + sdj) + 4 * second_formula + 24 * B
+        bm = wl["adj2"]._bitmap
+        probe = (4 * sdi if bm is not None else 0)                 # one 4-byte word of the bit row per neighbour of i
+        flags_comp = 4 * (sdi + sdj) + (probe if bm is not None else 4 * second_formula) + sdi + 16 * touched_cols + 24 * B
+    gather_formula = 4 * H * c12 + 8 * H * B + 4 * B
+    n_w1 = int((cnt1 > 0).sum())
+    gather_comp = (4 * H * distinct_h + 16 * touched_cols + 5 * pooled_rows_walked
+                   + 4 * H * (n_w1 + int(has_any.sum()) + B) + 24 * B)
+    return dict(flags_formula=flags_formula, flags_compulsory=flags_comp, gather_formula=gather_formula,
+                gather_compulsory=gather_comp, mean_di=sdi / B, mean_dj=sdj / B, mean_second=second_formula / B,
+                mean_c1=cnt1.float().mean().item(), mean_c2=cnt2.float().mean().item(),
+                distinct_h_rows=distinct_h, touched_cols=touched_cols,
+                frac_rows_cn1=n_w1 / B, frac_rows_any=float(has_any.float().mean()),
+                n_cn1=n_w1, n_any=int(has_any.sum()), n_cn2=int((cnt2 > 0).sum()))
 
 
-def cpu_baseline(wl, args):
-    """The oracle (a port of the reference's op sequence, torch CPU ops, the host cores this process
-    may use) on a bounded sample: the first ``b`` edges of the batch as a batch of their own."""
+def cpu_baseline(wl, args, mine):
+    """The oracle (a port of the reference's op sequence on torch CPU ops, oracle/ocn_oracle.py) timed on the
+    host cores of this box on the step's FULL candidate batch (or --cpu-sample edges of it), the adjacency's
+    rowptr cached as torch_sparse caches it.  The thread count is swept on a 1/8 sample (8 / 32 / 64 / all the
+    cores this process may use) and the full batch is then timed once with the fastest."""
     from oracle import ocn_oracle as O
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()
-    torch.set_num_threads(ncores)
     cfg, adj, adj2 = wl["cfg"], wl["adj"], wl["adj2"]
     r, c, _ = adj.coo()
     oadj = O.SpM(r.cpu(), c.cpu(), None, wl["n"], wl["n"])
+    oadj.rowptr()
     oadj2 = None
     if adj2 is not None:
         r2, c2, _ = adj2.coo()
         oadj2 = O.SpM(r2.cpu(), c2.cpu(), None, wl["n"], wl["n"])
+        oadj2.rowptr()
     h = wl["h"].cpu()
     sd = {k: v.detach().cpu() for k, v in wl["pred"].state_dict().items()}
 
     def run(b):
-        e = wl["edges"][:, :b].cpu()
+        e = mine[:, :b].cpu()
         t0 = time.time()
         if oadj2 is None:
             cn1, cn2 = O.get_cn1_cn2(oadj, e)
         else:
             cn1, cn2 = O.adjoverlap(oadj, oadj, e), O.adjoverlap(oadj, oadj2, e)
         if cfg["pred"] == "cn5":
-            out = O.cn5_forward(sd, h, cn1, cn2, e, ln=True, tailact=True)
+            out = O.cn5_forward(sd, h, cn1, cn2, e, ln=cfg["lnnn"])
         else:
-            out = O.cn7_forward(sd, h, cn1, cn2, e, cfg["sum"], ln=True, tailact=True)
+            out = O.cn7_forward(sd, h, cn1, cn2, e, cfg["sum"], ln=cfg["lnnn"])
         return time.time() - t0, out
 
-    b = min(args.cpu_sample, wl["edges"].shape[1])
-    t, out = run(b)
-    while t < 6.0 and b * 2 <= min(wl["edges"].shape[1], 16384):
-        b *= 2
-        t, out = run(b)
+    full = mine.shape[1] if not args.cpu_sample else min(args.cpu_sample, mine.shape[1])
+    probe = max(full // 8, min(full, 256))
+    sweep = {}
+    for nt in sorted({t for t in (8, 32, 64, ncores) if t <= ncores} | {min(8, ncores)}):
+        torch.set_num_threads(nt)
+        run(min(probe, 256))                              # thread pool warm-up
+        sweep[nt] = probe / run(probe)[0]
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    t, out = run(full)
     builder = "get_cn1_cn2" if oadj2 is None else "adjoverlap x2"
-    return dict(value=b / t, unit="edges/s", cores=ncores, kind="port",
-                sample=f"first {b} edges of the step's batch as one batch, oracle/ocn_oracle.py {builder} + "
-                       f"{cfg['pred']}_forward, {t:.2f} s, torch {torch.get_num_threads()} threads"), b, out
+    return dict(value=full / t, unit="edges/s", cores=best, kind="port",
+                sample=f"the step's {'full ' if full == mine.shape[1] else ''}{full}-edge batch as one batch, "
+                       f"oracle/ocn_oracle.py {builder} + {cfg['pred']}_forward (rowptr cached), {t:.2f} s with {best} torch "
+                       f"threads of {ncores} usable cores; thread sweep on {probe} edges: "
+                       + ", ".join(f"{k}t {v:.0f} e/s" for k, v in sorted(sweep.items()))), full, out
 
 
-def pmc_traffic(kernel_substr):
-    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r*_pmc.json:
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the default command).  FETCH_SIZE is
-    doubled (gfx950 counts 128-B requests as 64 B — MI355X_MICROARCH.md §HBM; calibrated on
+def pmc_traffic(dataset, kernel_substr):
+    """HBM-side bytes per launch of a kernel from the committed PMC passes (profiles/r*_pmc_<config>.json, or
+    r*_pmc.json for the default config: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command).
+    FETCH_SIZE is doubled (gfx950 counts 128-B requests as 64 B — MI355X_MICROARCH.md §HBM; calibrated on
     rows_ln_relu / combine3 whose byte counts are known exactly), both are in KiB."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{dataset}.json")))
+    if not files and dataset == "collab":
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
     if not files:
         return None
+    best = None
     for k, v in json.load(open(files[-1])).items():
         if kernel_substr in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            return (2.0 * v["FETCH_SIZE"]["avg"] + v["WRITE_SIZE"]["avg"]) * 1024.0
-    return None
+            t = (2.0 * v["FETCH_SIZE"]["avg"] + v["WRITE_SIZE"]["avg"]) * 1024.0
+            best = t if best is None else max(best, t)
+    return best
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--config", "--dataset", dest="dataset", default="collab", choices=sorted(CONFIGS))
     ap.add_argument("--predictor", default=None)
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--hiddim", type=int, default=None)
     ap.add_argument("--scale", type=float, default=1.0)
-    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--batches", type=int, default=8, help="distinct seeded candidate batches the timed steps rotate over")
+    ap.add_argument("--innerprod", type=float, default=0.0, help="value of the predictor's innerprod buffer (0 = fresh model)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="edges of the batch the CPU baseline runs (0 = the full batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
+    ap.add_argument("--no-validate-leg", action="store_true", help="skip the second timed loop with the per-batch id check on")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as a captured HIP graph (pipeline.GraphedScorer; one GPU, no stage events: "
-                         "the roofline objects are then null); small-batch configurations only (cora, ppa, citation2)")
+                         "the roofline objects are then null)")
     ap.add_argument("--prewarm", type=int, default=64, help="untimed runtime pre-warm steps before --warmup")
     ap.add_argument("--run-ahead", type=int, default=6, help="steps the host may enqueue ahead of the GPU")
-    ap.add_argument("--timer-every", type=int, default=8, help="record stage events on every n-th timed step")
+    ap.add_argument("--timer-every", type=int, default=5, help="record stage events on every n-th timed step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -253,147 +340,167 @@ def main():
     wl = build_workload(args, dev, rank, world)
     cfg, pred, h, adj = wl["cfg"], wl["pred"], wl["h"], wl["adj"]
     H = cfg["H"]
-    is_default = args.dataset == "collab" and args.scale == 1.0 and not (args.predictor or args.batch or args.hiddim)
-    pmc = pmc_traffic if is_default else (lambda k: None)
-    B_total = wl["edges"].shape[1]
+    is_default = args.scale == 1.0 and not (args.predictor or args.batch or args.hiddim or args.innerprod)
+    pmc = partial(pmc_traffic, args.dataset) if is_default else (lambda k: None)
+    B_total = wl["edges"][0].shape[1]
     s, e = shard_bounds(B_total, world)[rank]
-    mine = wl["edges"][:, s:e].contiguous()
+    mines = [g[:, s:e].contiguous() for g in wl["edges"]]
+    NB = len(mines)
     pred.set_edge_sharding(None, enabled=world > 1)
 
-    def step():
+    def step(it=0):
         with torch.no_grad():
+            mine = mines[it % NB]
             c1, c2 = cn_handles(wl, mine)
             loc = pred(h, adj, c1, c2, mine, wl["args"])
             return gather_scores(loc, B_total)
 
-    out = step()                                   # validated once (bounds check + flag capacity)
+    for b in range(NB):                            # every batch validated once (bounds check + flag capacity)
+        out = step(b)
     torch.cuda.synchronize()
-    ops.validate_indices = False                   # same ids every step: no per-step host sync
+    ops.validate_indices = False                   # ids checked above, as pipeline.score_edges does for a whole split
     if args.graph:
         if world > 1:
             raise SystemExit("--graph is a single-GPU option")
         from ocn_amd.pipeline import GraphedScorer
-        scorer = GraphedScorer(pred, h, adj, wl.get("adj2"), mine.shape[1], wl["args"],
+        scorer = GraphedScorer(pred, h, adj, wl.get("adj2"), mines[0].shape[1], wl["args"],
                                route="walk" if cfg["route"] == "walk" else "pattern")
         eager_step = step
 
-        def step():
-            return scorer(mine)
-        assert torch.equal(step(), eager_step())
+        def step(it=0):
+            return scorer(mines[it % NB])
+        for b in range(NB):
+            assert torch.equal(step(b), eager_step(b))
         args.no_stage_timers = True
     # Runtime pre-warm (untimed, before the W warm-up steps): the HIP runtime grows its internal
     # command/signal pools in ~35 ms host stalls during the first ~1000 launches of a process; a short
     # --warmup would otherwise put one of them inside the timed region.
     for i in range(args.prewarm):
-        step()
+        step(i)
         if i % 4 == 3:
             torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    timer = None if args.no_stage_timers else StageTimer(pool=32 * (args.steps // args.timer_every + 1))
-    ops.stage_timer = timer
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # Flow control: the host enqueues a step several times faster than the GPU runs it.  Left alone, the
-    # HIP runtime lets ~1000 commands pile up and then blocks the host until the queue has drained
-    # completely (measured: 35 ms stalls, GPU idle at the end of each) — so the host waits on the event of
-    # the step `run_ahead` steps back, as a real scoring loop that consumes its scores would.
-    run_ahead = max(args.run_ahead, 1)
-    ring = [torch.cuda.Event() for _ in range(run_ahead)]
-    for ev in ring:
-        ev.record()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    t_wait = 0.0
-    for it in range(args.steps):
-        tw = time.perf_counter()
-        ring[it % run_ahead].synchronize()
-        t_wait += time.perf_counter() - tw
-        if timer:                                  # stage events on every `timer_every`-th step only: on a busy
-            timer.active = it % args.timer_every == 0   # host each hipEventRecord costs tens of microseconds
-            timer.mark("begin")
-        out = step()
-        if timer:
-            timer.mark("mlp_glue")
-        ring[it % run_ahead].record()
-        if os.environ.get("OCN_BENCH_DEBUG"):
-            print("step", it, round((time.perf_counter() - t0) * 1e3, 3), file=sys.stderr)
-    t_launch = time.perf_counter() - t0 - t_wait    # host time spent enqueueing the K steps (flow-control waits excluded)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    ops.stage_timer = None
-    if world > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = tmax.item()
+    for i in range(args.warmup):
+        step(i)
+
+    def timed_loop(steps, timer):
+        """EXACTLY `steps` steps between two barrier + synchronize brackets; returns (seconds, host enqueue seconds)."""
+        ops.stage_timer = timer
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        # Flow control: the host enqueues a step several times faster than the GPU runs it.  Left alone, the
+        # HIP runtime lets ~1000 commands pile up and then blocks the host until the queue has drained
+        # completely (measured: 35 ms stalls, GPU idle at the end of each) — so the host waits on the event of
+        # the step `run_ahead` steps back, as a real scoring loop that consumes its scores would.
+        run_ahead = max(args.run_ahead, 1)
+        ring = [torch.cuda.Event() for _ in range(run_ahead)]
+        for ev in ring:
+            ev.record()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t_wait = 0.0
+        out = None
+        for it in range(steps):
+            tw = time.perf_counter()
+            ring[it % run_ahead].synchronize()
+            t_wait += time.perf_counter() - tw
+            if timer:                                  # stage events on every `timer_every`-th step only: on a busy
+                timer.active = it % args.timer_every == 0   # host each hipEventRecord costs tens of microseconds
+                timer.mark("begin")
+            out = step(it)
+            if timer:
+                timer.mark("mlp_glue")
+            ring[it % run_ahead].record()
+        t_launch = time.perf_counter() - t0 - t_wait    # host time spent enqueueing (flow-control waits excluded)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ops.stage_timer = None
+        if world > 1:
+            tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = tmax.item()
+        return dt, t_launch, out
+
+    timer = None if args.no_stage_timers else StageTimer(pool=40 * (args.steps // args.timer_every + 1))
+    dt, t_launch, out = timed_loop(args.steps, timer)
+    # second leg: the per-batch id check left on (the drivers' literal loop: one host sync per batch)
+    dt_val = None
+    if not args.no_validate_leg and not args.graph:
+        ops.validate_indices = True
+        for i in range(4):
+            step(i)
+        dt_val, _, _ = timed_loop(min(args.steps, 64), None)
+        dt_val /= min(args.steps, 64)
+        ops.validate_indices = False
 
     if rank == 0:
-        from ocn_amd.utils import CNState
-        st = (CNState(adj, None, None, mine, walk=True) if cfg["route"] == "walk"
-              else CNState(adj, adj, wl["adj2"], mine))
-        ab = algorithmic_bytes(wl, mine, st.cnt1, st.cnt2, H)
+        per = [batch_bytes(wl, m, H) for m in mines]
+        ab = {k: sum(p[k] for p in per) / NB for k in per[0]}
         stages = {k: dict(ms=v[0], launches=v[1]) for k, v in (timer.totals() if timer else {}).items()}
-        roof, roof_hbm = None, None
+        sampled = len([1 for it in range(args.steps) if it % args.timer_every == 0])
+        roof, roof_hbm, roofs = None, None, {}
         if stages:
-            for k in ("cn_flags", "cn_gather"):
-                if k in stages:
-                    stages[k]["algorithmic_GBps"] = ab[k] / (stages[k]["ms"] * 1e-3) / 1e9
-            # dominant kernel = largest total time per step
-            sampled = len([1 for it in range(args.steps) if it % args.timer_every == 0])
             per_step = {k: v["ms"] * v["launches"] / sampled for k, v in stages.items()}
+            kname = {"cn_flags": "cn_walk_kernel" if cfg["route"] == "walk" else "cn_flags_kernel",
+                     "cn_gather": "cn_gather_wave_kernel" if (H <= 64 and mines[0].shape[1] * (H // 4) < 262144) else "cn_gather_kernel"}
+            for k, comp, form in (("cn_flags", "flags_compulsory", "flags_formula"), ("cn_gather", "gather_compulsory", "gather_formula")):
+                if k not in stages:
+                    continue
+                t = stages[k]["ms"] * 1e-3
+                tr = pmc(kname[k])
+                roofs[k] = dict(bound="hbm", kernel=kname[k], achieved=ab[comp] / t / 1e9, peak=HBM_PEAK / 1e9, unit="GB/s",
+                                frac=ab[comp] / t / HBM_PEAK, traffic=tr,
+                                traffic_frac=None if tr is None else tr / t / HBM_PEAK,
+                                algorithmic_bytes_per_launch=ab[comp], survey_formula_bytes_per_launch=ab[form],
+                                survey_formula_GBps=ab[form] / t / 1e9, avg_launch_ms=stages[k]["ms"],
+                                note="achieved = compulsory bytes of the batch (distinct embedding / weight rows once, "
+                                     "CSR rows walked, outputs) / launch time; the SURVEY §8d formula (one row per CN "
+                                     "entry, whole A² row) is printed beside it and may exceed the HBM peak because "
+                                     "shared rows are served by L2; traffic = PMC 2*FETCH_SIZE + WRITE_SIZE of the "
+                                     "committed profile")
+                stages[k]["compulsory_GBps"] = roofs[k]["achieved"]
             dom = max((k for k in ("cn_flags", "cn_gather", "linear") if k in stages), key=lambda k: per_step[k])
-            g = "cn_gather"
-            roof_hbm = dict(bound="hbm", kernel="cn_gather_kernel", achieved=ab[g] / (stages[g]["ms"] * 1e-3) / 1e9,
-                            peak=HBM_PEAK / 1e9, unit="GB/s", frac=ab[g] / (stages[g]["ms"] * 1e-3) / HBM_PEAK,
-                            traffic=pmc("cn_gather_kernel"), algorithmic_bytes_per_launch=ab[g],
-                            avg_launch_ms=stages[g]["ms"],
-                            note="algorithmic bytes price one embedding row per CN entry; rows shared by "
-                                 "candidates processed together are served by L2, so frac can exceed 1")
+            roof_hbm = roofs.get("cn_gather")
             if dom == "linear":
                 # f32 FLOPs of the Linear layers per launch.  With the zero-row skipping of the heads the
                 # launches cover only part of the batch (device-side row ranges): count the rows they do.
+                launches_per_step = stages["linear"]["launches"] / sampled
                 fl = timer.flops.get("linear", 0.0) / stages["linear"]["launches"]
                 skip = getattr(pred, "_skip_state", None)
+                Bm = mines[0].shape[1]
                 skipping = bool(ops.skip_zero_rows and skip is not None and skip["off"] == 0
-                                and mine.shape[1] >= ops.skip_zero_min_batch and pred._heads_plan(H) is not None)
+                                and Bm >= ops.skip_zero_min_batch and pred._heads_plan(H) is not None)
                 if skipping:
-                    Bm = mine.shape[1]
-                    n_cn1 = int((st.cnt1 > 0).sum())
-                    n_any = int(((st.cnt1 > 0) | (st.cnt2 > 0)).sum())
-                    n_b = n_any if pred._xcn2_on_union else int((st.cnt2 > 0).sum())
+                    n_cn1, n_any = ab["n_cn1"], ab["n_any"]
+                    n_b = n_any if pred._xcn2_on_union else ab["n_cn2"]
                     sx_layers = len(pred._heads_plan(H)[2])
                     lin_layers = sum(1 for m in pred.lin if isinstance(m, torch.nn.Linear) and m.out_features == H)
                     executed = 2.0 * H * H * (2 * n_cn1 + 2 * n_b + sx_layers * Bm + lin_layers * Bm) + 2.0 * (2 * H) * H * n_any
-                    fl = executed / (stages["linear"]["launches"] / sampled)
+                    fl = executed / launches_per_step
                 t = stages["linear"]["ms"] * 1e-3
                 roof = dict(bound="mfma", kernel="linear_bf16x6_kernel", achieved=fl / t / 1e12,
                             peak=F32_MFMA_PEAK / 1e12, unit="TFLOP/s", frac=fl / t / F32_MFMA_PEAK,
                             traffic=pmc("linear_bf16x6_kernel"),
                             algorithmic_flops_per_launch=fl, avg_launch_ms=stages["linear"]["ms"],
-                            launches_per_step=stages["linear"]["launches"] / sampled,
+                            launches_per_step=launches_per_step,
                             executed_bf16_tflops=6 * fl / t / 1e12, executed_frac_of_bf16_peak=6 * fl / t / BF16_MFMA_PEAK,
                             skipped_zero_rows=skipping,
-                            note="per-launch averages over the grouped launches of a step (3 + 2 + 2 + 1 Linear(H,H) "
-                                 "equivalents, less the rows whose pooled input is all zero when skipped_zero_rows); "
-                                 "f32 Linear evaluated as six bf16 MFMA cross terms: achieved/peak are the "
-                                 "algorithmic f32 FLOPs against the dense f32 MFMA peak; executed_* count the "
-                                 "bf16 MFMAs actually issued against the dense bf16 peak")
+                            note="per-launch averages over the Linear launches of a step (" + head_layout(pred) + "; less "
+                                 "the rows whose pooled input is all zero when skipped_zero_rows); f32 Linear evaluated "
+                                 "as six bf16 MFMA cross terms: achieved/peak are the algorithmic f32 FLOPs against "
+                                 "the dense f32 MFMA peak; executed_* count the bf16 MFMAs actually issued against "
+                                 "the dense bf16 peak")
             else:
-                kname = "cn_walk_kernel" if cfg["route"] == "walk" else "cn_flags_kernel"
-                roof = dict(roof_hbm) if dom == g else dict(
-                    bound="hbm", kernel=kname, achieved=ab[dom] / (stages[dom]["ms"] * 1e-3) / 1e9,
-                    peak=HBM_PEAK / 1e9, unit="GB/s", frac=ab[dom] / (stages[dom]["ms"] * 1e-3) / HBM_PEAK,
-                    traffic=pmc(kname), algorithmic_bytes_per_launch=ab[dom], avg_launch_ms=stages[dom]["ms"])
+                roof = roofs[dom]
         cpu, err = None, None
         if world == 1 and not args.no_cpu_baseline:
-            cpu, b, ref = cpu_baseline(wl, args)
+            cpu, b, ref = cpu_baseline(wl, args, mines[0])
             ops.validate_indices = False
-            sub = mine[:, :b].contiguous()
+            sub = mines[0][:, :b].contiguous()
             with torch.no_grad():
                 c1, c2 = cn_handles(wl, sub)
                 got = pred(h, adj, c1, c2, sub, wl["args"]).cpu()
@@ -405,18 +512,27 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ogbl-{args.dataset}-shaped synthetic graph, {cfg['enc']} {cfg['conv']} x{cfg['layers']} "
-                                   f"hiddim={H} predictor={cfg['pred']} CN route={cfg['route']} batch {cfg['batch']} per GPU "
-                                   f"(BASELINE.json configs[{idx}])",
+                                   f"hiddim={H} predictor={cfg['pred']} built as the reference drivers build it (only cndeg "
+                                   f"forwarded: tailact=False, use_xlin=False, beta=1, lnnn={cfg['lnnn']}; head = "
+                                   f"{head_layout(pred)}), CN route={cfg['route']}, batch {cfg['batch']} per GPU, "
+                                   f"{NB} distinct seeded batches in rotation, ids bounds-checked once before the timed "
+                                   f"region (BASELINE.json configs[{idx}])",
                        "nodes": wl["n"], "nnz": wl["nnz"], "nnz_A2": wl["nnz2"], "max_deg": wl["max_deg"],
                        "global_batch": B_total, "parallelism": f"edge-shard x{world}", "graph_scale": args.scale,
+                       "batches_in_rotation": NB, "innerprod": args.innerprod,
                        "mean_deg_src": ab["mean_di"], "mean_deg_dst": ab["mean_dj"],
                        "mean_second_operand_len": ab["mean_second"],
-                       "mean_cn1": ab["mean_c1"], "mean_cn2": ab["mean_c2"]},
-            "roofline": roof, "roofline_hbm_kernel": roof_hbm, "cpu_baseline": cpu,
+                       "mean_cn1": ab["mean_c1"], "mean_cn2": ab["mean_c2"],
+                       "distinct_h_rows_per_batch": ab["distinct_h_rows"],
+                       "frac_rows_with_cn1": ab["frac_rows_cn1"], "frac_rows_with_any_cn": ab["frac_rows_any"]},
+            "roofline": roof, "roofline_hbm_kernel": roof_hbm, "rooflines": roofs, "cpu_baseline": cpu,
+            "value_validate_per_batch": None if dt_val is None else B_total / dt_val,
+            "ms_per_step_validate_per_batch": None if dt_val is None else dt_val * 1e3,
             "stages": stages,
             "once_per_graph": {"encoder_ms": wl["enc_s"] * 1e3, "adj2_build_ms": wl["a2_s"] * 1e3,
                                "graph_build_s": wl["graph_s"]},
-            "algorithmic_bytes_per_step": ab["total"],
+            "algorithmic_bytes_per_step": ab["flags_compulsory"] + ab["gather_compulsory"],
+            "survey_formula_bytes_per_step": ab["flags_formula"] + ab["gather_formula"],
             "host_enqueue_ms_per_step": t_launch / args.steps * 1e3,
             "parity_on_cpu_sample_max_abs_err": err,
             "score_checksum": float(out.double().sum().item()),

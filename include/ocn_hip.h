@@ -43,6 +43,13 @@ int64_t ocn_scan_workspace_bytes(int64_t n);
 int ocn_edge_offsets(const int64_t* rowptrA, const int64_t* src, int64_t B,
                      int64_t* off, void* workspace, void* stream);
 
+/* bad[0] |= 1 when any src[e] is outside [0, n_src) or any dst[e] outside [0, n_dst) (bad[0] is NOT
+ * cleared here).  The reference's row selection raises IndexError for such an id
+ * (SparseTensor.__getitem__ -> index_select, utils.py:256-257); the kernels below would read out of
+ * bounds instead, so the Python mirror runs this check first and raises the same exception. */
+int ocn_check_edges(const int64_t* src, const int64_t* dst, int64_t B, int64_t n_src, int64_t n_dst,
+                    int32_t* bad, void* stream);
+
 /* A processing order for a candidate batch: order[] = the batch rows counting-sorted by the node id
  * in `node` (arbitrary order among equal ids).  Visiting rows with the same / nearby source node
  * together lets the rows they share be served from L2; it never changes a result.
@@ -221,8 +228,8 @@ int ocn_spgemm_pattern_fill(const int64_t* rowptrA, const int32_t* colA, int64_t
                             const int64_t* rowptrB, const int32_t* colB, int64_t n_colsB,
                             const int64_t* rowptrC, int32_t* colC, void* stream);
 
-/* Glue between the dense Linear layers of the MLP heads (model.py:2203-2235, 2429-2437), which
- * stay library GEMMs: y = LayerNorm(x) (eps, affine gamma/beta) followed by ReLU when `relu` != 0,
+/* Glue for head layouts the fused Linear kernel below does not cover (widths outside 32..256, training
+ * mode; model.py:2203-2235, 2429-2437): y = LayerNorm(x) (eps, affine gamma/beta) followed by ReLU when `relu` != 0,
  * one pass over [rows][H] (replaces nn.LayerNorm + Dropout(eval) + nn.ReLU); and the branch mix
  * out = c[0]*x1 + c[1]*x2 + c[2]*x3 with the three coefficients read from device memory
  * (alpha.sigmoid().cumprod() and beta, model.py:2435-2436).  H in {16..512, power of two}. */

@@ -22,6 +22,7 @@ _P = c_void_p
 SIGNATURES = {
     "ocn_abi_version": (c_int32, []),
     "ocn_scan_workspace_bytes": (c_int64, [c_int64]),
+    "ocn_check_edges": (c_int32, [_P, _P, c_int64, c_int64, c_int64, _P, _P]),
     "ocn_edge_offsets": (c_int32, [_P, _P, c_int64, _P, _P, _P]),
     "ocn_class_order": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "ocn_scan_i32": (c_int32, [_P, c_int64, _P, _P, _P]),

@@ -286,8 +286,10 @@ __device__ __forceinline__ void walk_sweep(const int32_t* __restrict__ colA, con
         }
       }
     }
-    __syncthreads();
-    if (*s_nq > WALK_Q / 2 || x0 + WU * WALK_THREADS >= total) {
+    // The flush decision must be workgroup-uniform (the branch holds barriers): every thread reads
+    // the queue fill inside the barrier itself, before any wave can append for the next round.
+    const int flush = __syncthreads_or(*s_nq > WALK_Q / 2 || x0 + WU * WALK_THREADS >= total);
+    if (flush) {
       const int nq = *s_nq < WALK_Q ? *s_nq : WALK_Q;
       for (int q = threadIdx.x; q < nq; q += WALK_THREADS) {
         const i64 pos = sorted_find(set_g, ds, s_qk[q]);
@@ -1159,7 +1161,10 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
   // LH: a persistent grid (a few workgroups per CU) so that each LDS histogram absorbs many edges
   const int grid = lh ? grid_for((B + GPB - 1) / GPB, 256 * 3) : grid_for((B + GPB - 1) / GPB);
   if (lh) {                                   // static (target rows) + dynamic (histogram) LDS can pass 64 KiB
-    static bool raised = false;
+    static bool raised_dev[64] = {};          // the attribute is per device (function objects are per device)
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return OCN_EINVAL;
+    bool& raised = raised_dev[devid];
     if (!raised) {
       hipError_t e1 = hipFuncSetAttribute((const void*)cn_flags_kernel<OCN_X_G, true, true>,
                                           hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -195,6 +195,12 @@ static int run_scan(Op op, i64 n, i64* out, void* ws, hipStream_t st) {
 // order among rows with the same source), so that rows that gather the same neighbourhood are
 // visited back to back
 // ---------------------------------------------------------------------------------------------
+// (a kernel rather than hipMemsetAsync: the library then enqueues nothing but kernel nodes, so a captured
+// candidate batch replays as a pure kernel graph)
+__global__ __launch_bounds__(OCN_BLOCK) void zero_i32_kernel(int32_t* __restrict__ p, i64 n) {
+  for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (i64)gridDim.x * blockDim.x) p[q] = 0;
+}
+
 __global__ __launch_bounds__(OCN_BLOCK) void order_count(const i64* __restrict__ node, i64 B,
                                                          int32_t* __restrict__ counts) {
   for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < B; e += (i64)gridDim.x * blockDim.x)
@@ -208,9 +214,28 @@ __global__ __launch_bounds__(OCN_BLOCK) void order_scatter(const i64* __restrict
     order[atomicAdd(cursor + node[e], 1ull)] = e;
 }
 
+__global__ __launch_bounds__(OCN_BLOCK) void check_edges_kernel(const i64* __restrict__ src, const i64* __restrict__ dst,
+                                                               i64 B, i64 n_src, i64 n_dst, int32_t* __restrict__ bad) {
+  bool b = false;
+  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < B; e += (i64)gridDim.x * blockDim.x) {
+    const i64 i = src[e], j = dst[e];
+    b |= (i < 0) | (i >= n_src) | (j < 0) | (j >= n_dst);
+  }
+  if (__ballot(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
+}
+
 extern "C" {
 
 int64_t ocn_scan_workspace_bytes(int64_t n);
+
+int ocn_check_edges(const int64_t* src, const int64_t* dst, int64_t B, int64_t n_src, int64_t n_dst, int32_t* bad,
+                    void* stream) {
+  if (B < 0 || !bad || (B > 0 && (!src || !dst))) return OCN_EINVAL;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(check_edges_kernel, dim3(grid_for((B + OCN_BLOCK - 1) / OCN_BLOCK, 1024)), dim3(OCN_BLOCK), 0,
+                     (hipStream_t)stream, (const i64*)src, (const i64*)dst, (i64)B, (i64)n_src, (i64)n_dst, bad);
+  return launch_status();
+}
 
 static inline i64 order_counts_bytes(i64 n_nodes) { return ((n_nodes * 4 + 15) / 16) * 16; }
 
@@ -227,8 +252,8 @@ int ocn_order_by_node(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* 
   int32_t* counts = (int32_t*)workspace;
   i64* offs = (i64*)((char*)workspace + order_counts_bytes(n_nodes));
   void* scan_ws = (void*)(offs + n_nodes + 1);
-  hipError_t err = hipMemsetAsync(counts, 0, (size_t)n_nodes * 4, st);
-  if (err != hipSuccess) return (int)err;
+  hipLaunchKernelGGL(zero_i32_kernel, dim3(grid_for((n_nodes + OCN_BLOCK - 1) / OCN_BLOCK, 1024)), dim3(OCN_BLOCK), 0, st,
+                     counts, (i64)n_nodes);
   const int grid = grid_for((B + OCN_BLOCK - 1) / OCN_BLOCK, 1024);
   hipLaunchKernelGGL(order_count, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)node, (i64)B, counts);
   I32In op{counts};

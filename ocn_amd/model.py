@@ -4,8 +4,9 @@ Exports ``predictor_dict`` (``cn5`` = CNLinkPredictorOringin, model.py:2171-2443
 CNLinkPredictorbaselearn, model.py:3021-3229), ``convdict`` / ``convdict2`` / ``convdict3``,
 ``GCN`` / ``GCN2`` / ``GCN3`` (model.py:232-511), ``PureConv*``, ``DropAdj``, ``DropEdge`` with the
 reference's constructor signatures and ``state_dict`` key layout, so checkpoints and the unchanged
-drivers work.  The sparse arithmetic runs in libocn_hip.so (no torch_sparse / pygho / PyG); the
-dense ``Linear`` / ``LayerNorm`` heads stay torch modules (rocBLAS fp32).
+drivers work.  The sparse arithmetic runs in libocn_hip.so (no torch_sparse / pygho / PyG); in eval the
+dense ``Linear`` / ``LayerNorm`` / ``ReLU`` heads run on the bf16x6 MFMA kernel of the same library
+(``_seq_eval`` / ``_heads_grouped``), the ``nn`` modules only hold the parameters (and run under autograd).
 """
 from __future__ import annotations
 
@@ -477,6 +478,8 @@ class _CNPredictorBase(nn.Module):
         pr = getattr(self, "_skip_state", None)
         if pr is None:
             return True
+        if torch.cuda.is_current_stream_capturing():     # no event query while capturing: replay what was last decided
+            return pr["off"] == 0
         if pr["pending"] is not None and pr["pending"].query():
             r = pr["host"]
             B = max(int(pr["B"]), 1)

@@ -27,6 +27,29 @@ walk_two_sided = True            # walk route: sweep each candidate from its che
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 
 
+def _on_device(fn):
+    """Launch on the device of the operands.  ``stream_ptr()`` is the current stream of the CURRENT
+    device; tensors living on another device (a predictor on cuda:1 in a process whose current device is
+    cuda:0) would otherwise be handed to a kernel enqueued on the wrong GPU.  Tensors on different
+    devices are an error, as they are for torch's own operators."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kw):
+        idx = -1
+        for a in args:
+            if isinstance(a, Tensor) and a.is_cuda:
+                if idx < 0:
+                    idx = a.device.index
+                elif a.device.index != idx:
+                    raise RuntimeError(f"{fn.__name__}: operands on different devices (cuda:{idx}, cuda:{a.device.index})")
+        if idx >= 0 and idx != torch._C._cuda_getDevice():
+            with torch.cuda.device(idx):
+                return fn(*args, **kw)
+        return fn(*args, **kw)
+    return wrapper
+
+
 def _mark(name: str, flops: float = 0.0) -> None:
     if stage_timer is not None:
         stage_timer.mark(name, flops)
@@ -65,6 +88,7 @@ def buf(ws, name: str, shape, dtype, device, zero: bool = False) -> Tensor:
     return t
 
 
+@_on_device
 def edge_offsets(rowptr: Tensor, src: Tensor, wsd=None) -> Tensor:
     _req(rowptr, torch.int64, "rowptr", 1)
     _req(src, torch.int64, "src", 1)
@@ -76,6 +100,7 @@ def edge_offsets(rowptr: Tensor, src: Tensor, wsd=None) -> Tensor:
     return off
 
 
+@_on_device
 def scan_i32(cnt: Tensor) -> Tensor:
     _req(cnt, torch.int32, "cnt", 1)
     n = cnt.numel()
@@ -85,15 +110,39 @@ def scan_i32(cnt: Tensor) -> Tensor:
     return out
 
 
+@_on_device
 def check_edges(src: Tensor, dst: Tensor, n_src: int, n_dst: int) -> None:
     """Reference behaviour for an out-of-range node id is an IndexError from index_select; a raw
     kernel would fault instead, so the ids are checked here (costs one host sync)."""
     if not validate_indices or src.numel() == 0:
         return
-    lo = torch.minimum(src.min(), dst.min())
-    bad = (lo < 0) | (src.max() >= n_src) | (dst.max() >= n_dst)
-    if bool(bad):
+    _req(src, torch.int64, "src", 1); _req(dst, torch.int64, "dst", 1)
+    bad = torch.zeros(1, dtype=torch.int32, device=src.device)
+    check(_lib.lib().ocn_check_edges(ptr(src), ptr(dst), src.numel(), int(n_src), int(n_dst), ptr(bad), stream_ptr()),
+          "ocn_check_edges")
+    if int(bad.item()):
         raise IndexError("candidate edge endpoint out of range for the adjacency")
+
+
+class prevalidated:
+    """``with ops.prevalidated(src_all, dst_all, n_src, n_dst):`` — bounds-check a whole split of candidate
+    edges once (one host sync), then run the batches inside without the per-batch check.  This is what
+    ``pipeline.score_edges`` / ``score_mrr_split`` do: the check is hoisted out of the batch loop, the
+    exception for a bad id is the same IndexError, raised before the first batch."""
+
+    def __init__(self, src: Tensor, dst: Tensor, n_src: int, n_dst: int):
+        check_edges(src.contiguous(), dst.contiguous(), n_src, n_dst)
+
+    def __enter__(self):
+        global validate_indices
+        self._keep = validate_indices
+        validate_indices = False
+        return self
+
+    def __exit__(self, *exc):
+        global validate_indices
+        validate_indices = self._keep
+        return False
 
 
 HIST_FIELD_BITS = 21             # hist word 0 packs n1 | n2 << 21 | n_union << 42
@@ -107,6 +156,7 @@ def hist_counts(hist: Tensor) -> Tensor:
     return torch.stack([p & m, (p >> HIST_FIELD_BITS) & m, (p >> (2 * HIST_FIELD_BITS)) & m, hist[:, 1]], dim=1)
 
 
+@_on_device
 def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
              t2: Optional[Tuple[Tensor, Tensor]], src: Tensor, dst: Tensor, n_cols: int, max_deg_a: int,
              walk: bool = False, t2_bitmap: Optional[Tensor] = None, wsd=None, nds: Optional[Tensor] = None):
@@ -181,6 +231,7 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     return order, off, flags, wc, hist, cnt1, cnt2, status
 
 
+@_on_device
 def neighbor_degree_sum(rowptr: Tensor, col: Tensor) -> Tensor:
     """nds[v] = Σ_{u∈N(v)} deg(u) (int64): the elements a sweep of v's neighbour rows touches."""
     _req(rowptr, torch.int64, "rowptr", 1); _req(col, torch.int32, "col", 1)
@@ -191,6 +242,7 @@ def neighbor_degree_sum(rowptr: Tensor, col: Tensor) -> Tensor:
     return out
 
 
+@_on_device
 def cn_weights_cn5(hist: Tensor, innerprod: Tensor, valued: bool = False, wsd=None) -> Tensor:
     """In place: packed int64 [N,2] histogram -> float32 [N,4] weights {w1, t, inv2, 0} (same storage)."""
     _req(hist, torch.int64, "hist", 2)
@@ -202,6 +254,7 @@ def cn_weights_cn5(hist: Tensor, innerprod: Tensor, valued: bool = False, wsd=No
     return hist.view(torch.float32)
 
 
+@_on_device
 def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
     _req(hist, torch.int64, "hist", 2)
     check(_lib.lib().ocn_cn_weights_cn7(ptr(hist), hist.shape[0], float(sum_fill), stream_ptr()),
@@ -210,6 +263,7 @@ def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
     return hist.view(torch.float32)
 
 
+@_on_device
 def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights: Tensor, h: Tensor,
               order: Optional[Tensor] = None, max_row_len: int = 0, wsd=None, out_row: Optional[Tensor] = None,
               cnt1: Optional[Tensor] = None, cnt2: Optional[Tensor] = None):
@@ -230,6 +284,7 @@ CLASS_RANGES = 7                 # include/ocn_hip.h: OCN_CLASS_RANGES
 R_CN1, R_BOTH, R_CN2_ONLY, R_ANY, R_NONE, R_CN1_ONLY, R_ALL = range(CLASS_RANGES)
 
 
+@_on_device
 def class_order(cnt1: Tensor, cnt2: Optional[Tensor], order: Optional[Tensor], wsd=None):
     """Class-major processing order for the heads (ocn_hip.h: ocn_class_order).
     Returns (order2 [B] slot -> batch row, inv [B] batch row -> slot, ranges int64 [7, 2] on the device)."""
@@ -247,6 +302,7 @@ def class_order(cnt1: Tensor, cnt2: Optional[Tensor], order: Optional[Tensor], w
     return order2, inv, ranges
 
 
+@_on_device
 def cn_weights_cn6(histA: Tensor, histB: Tensor, innerprod: Tensor):
     """In place: histA -> float32 [N,4] {inv1, t, inv2, 0}, histB -> {1/S3, 0, 0, 0}; returns them and the
     device scalar nip (ocn_hip.h: ocn_cn_weights_cn6)."""
@@ -262,6 +318,7 @@ def cn_weights_cn6(histA: Tensor, histB: Tensor, innerprod: Tensor):
     return histA.view(torch.float32).view(-1, 4), histB.view(torch.float32).view(-1, 4), nip
 
 
+@_on_device
 def cn_gather3(rowptrA, colA, src, dst, off, flagsA, flagsB, wA: Tensor, wB: Tensor, nip: Tensor, h: Tensor,
                order: Optional[Tensor] = None):
     """(xcn1, xcn2, xcn3, x_i * x_j) of the 3-hop predictor."""
@@ -280,6 +337,7 @@ def cn_gather3(rowptrA, colA, src, dst, off, flagsA, flagsB, wA: Tensor, wB: Ten
     return out[0], out[1], out[2], out[3]
 
 
+@_on_device
 def cn_gather_backward(rowptrA, colA, src, dst, off, flags, wc, weights: Tensor, h: Tensor, g1: Tensor, g2: Tensor,
                        g3: Tensor, order: Optional[Tensor] = None) -> Tensor:
     """Gradient of (xcn1, xcn2, xij) with respect to h."""
@@ -299,6 +357,7 @@ def cn_gather_backward(rowptrA, colA, src, dst, off, flags, wc, weights: Tensor,
 SPMM_MODES = {"sum": 0, "add": 0, "mean": 1, "max": 2}
 
 
+@_on_device
 def spmm_csr(rowptr: Tensor, col: Tensor, x: Tensor, pre: Optional[Tensor] = None,
              post: Optional[Tensor] = None, mode: str = "sum", edge_scale: bool = False,
              self_mode: int = 0, val: Optional[Tensor] = None) -> Tensor:
@@ -320,6 +379,7 @@ def spmm_csr(rowptr: Tensor, col: Tensor, x: Tensor, pre: Optional[Tensor] = Non
     return y
 
 
+@_on_device
 def deg_rsqrt(rowptr: Tensor, add: float = 1.0, val: Optional[Tensor] = None) -> Tensor:
     _req(rowptr, torch.int64, "rowptr", 1)
     n = rowptr.numel() - 1
@@ -328,6 +388,7 @@ def deg_rsqrt(rowptr: Tensor, add: float = 1.0, val: Optional[Tensor] = None) ->
     return out
 
 
+@_on_device
 def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int):
     """CSR pattern of A·B (columns ascending) and, when it fits ``a2_bitmap_max_bytes``, the same
     rows as dense bit rows.  One host sync for the output size."""
@@ -356,6 +417,7 @@ def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int):
     return rowptrC, colC, bitmap
 
 
+@_on_device
 def rows_ln_relu(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu: bool, inplace: bool = False) -> Tensor:
     """LayerNorm over the last dim of a [rows, H] fp32 matrix, optionally followed by ReLU."""
     _req(x, torch.float32, "x", 2)
@@ -369,6 +431,7 @@ def rows_ln_relu(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu: bool,
     return y
 
 
+@_on_device
 def combine3(coef: Tensor, x1: Tensor, x2: Tensor, x3: Tensor) -> Tensor:
     """coef[0]*x1 + coef[1]*x2 + coef[2]*x3 with the coefficients read on the device."""
     _req(coef, torch.float32, "coef", 1)
@@ -382,6 +445,7 @@ def combine3(coef: Tensor, x1: Tensor, x2: Tensor, x3: Tensor) -> Tensor:
     return out
 
 
+@_on_device
 def fill_rows(dst: Tensor, vec: Tensor, row_range: Tensor) -> None:
     """dst[rows of the device-side range] = vec (dst may be a column slice of a wider buffer)."""
     _req_strided(dst, "dst")
@@ -399,6 +463,7 @@ fast_linear = True               # route eligible nn.Linear layers of the heads 
 _panels: dict = {}
 
 
+@_on_device
 def linear_panel(weight: Tensor) -> Tensor:
     """Pre-split, fragment-ordered bf16 panel of an nn.Linear weight.  Cached per live tensor object
     (weak reference) and rebuilt when the weight is modified in place (``_version``), re-pointed
@@ -426,6 +491,7 @@ def linear_ok(x: Tensor, weight: Tensor) -> bool:
             and weight.shape[0] in LINEAR_WIDTHS and weight.shape[1] % 16 == 0 and weight.shape[1] == x.shape[1])
 
 
+@_on_device
 def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln=None, relu: bool = False,
            dot=None, y_row_map: Optional[Tensor] = None) -> Tensor:
     """epilogue(x @ weight.T + bias): optional LayerNorm ``ln=(gamma, beta, eps)``, ReLU, and a
@@ -466,6 +532,10 @@ def linear_grouped(groups, K: int, N: int) -> None:
     [begin, end) of the buffers), y_row_map (device int64[M]: destination row of the dot output)."""
     if not 1 <= len(groups) <= 5:
         raise ValueError("1..5 groups")
+    idx = groups[0]["x"].device.index
+    if idx is not None and idx != torch._C._cuda_getDevice():
+        with torch.cuda.device(idx):
+            return linear_grouped(groups, K, N)
     arr = (_lib.OcnLinearGroup * len(groups))()
     keep = []
     for a, g in zip(arr, groups):

@@ -34,13 +34,17 @@ def score_edges(predictor, h: Tensor, adj, adj2, edges: Tensor, batch_size: int,
         raise RuntimeError("score_edges is the eval path; call predictor.eval() first")
     h = h.contiguous()
     outs, done = [], []
-    for perm in PermIterator(edges.device, edges.shape[0], batch_size, training=False):
-        if len(done) >= max(run_ahead, 1):
-            done.pop(0).synchronize()
-        e = edges[perm].t().contiguous()
-        outs.append(predictor(h, adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e), e, args).reshape(-1))
-        done.append(torch.cuda.current_stream(h.device).record_event())
-    return torch.cat(outs, dim=0) if outs else h.new_zeros(0)
+    if edges.shape[0] == 0:
+        return h.new_zeros(0)
+    # the ids of the whole split are bounds-checked once; the batches then run without a host sync each
+    with ops.prevalidated(edges[:, 0], edges[:, 1], adj.size(0), adj.size(0)):
+        for perm in PermIterator(edges.device, edges.shape[0], batch_size, training=False):
+            if len(done) >= max(run_ahead, 1):
+                done.pop(0).synchronize()
+            e = edges[perm].t().contiguous()
+            outs.append(predictor(h, adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e), e, args).reshape(-1))
+            done.append(torch.cuda.current_stream(h.device).record_event())
+    return torch.cat(outs, dim=0)
 
 
 @torch.no_grad()
@@ -57,11 +61,14 @@ def score_mrr_split(predictor, h: Tensor, adj, source: Tensor, target: Tensor, t
 
     def run(src_all: Tensor, dst_all: Tensor) -> Tensor:
         outs = []
-        for perm in PermIterator(src_all.device, src_all.shape[0], batch_size, training=False):
-            e = torch.stack((src_all[perm], dst_all[perm]))
-            cn1, cn2 = get_cn1_cn2(adj, e)
-            outs.append(predictor(h, adj, cn1, cn2, e, args).reshape(-1))
-        return torch.cat(outs, dim=0) if outs else h.new_zeros(0)
+        if src_all.numel() == 0:
+            return h.new_zeros(0)
+        with ops.prevalidated(src_all, dst_all, adj.size(0), adj.size(0)):
+            for perm in PermIterator(src_all.device, src_all.shape[0], batch_size, training=False):
+                e = torch.stack((src_all[perm], dst_all[perm]))
+                cn1, cn2 = get_cn1_cn2(adj, e)
+                outs.append(predictor(h, adj, cn1, cn2, e, args).reshape(-1))
+        return torch.cat(outs, dim=0)
 
     pos_pred = run(source, target)
     n_neg = target_neg.shape[1]

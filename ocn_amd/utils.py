@@ -197,6 +197,16 @@ class CNState3:
                               self.b.flags, wa, wb, nip, h, order=self.a.order)
 
 
+def _same_edges(a: Tensor, b: Tensor) -> bool:
+    """The drivers hand the SAME tensor to both adjoverlap calls and to the predictor
+    (NeighborOverlap_large.py:121-159): identity (or the same view of one storage) needs no device
+    comparison, anything else costs a torch.equal (one host sync)."""
+    if a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
+                  and a.dtype == b.dtype and a.device == b.device):
+        return True
+    return torch.equal(a, b)
+
+
 def fuse3(cn1: "CNBatch", cn2: "CNBatch", cn3: "CNBatch", tar_ei: Tensor) -> CNState3:
     """(cn1, cn2, cn3) = adjoverlap(adj, adj | adj2 | adj3, e) of one candidate batch."""
     for c in (cn1, cn2, cn3):
@@ -204,8 +214,8 @@ def fuse3(cn1: "CNBatch", cn2: "CNBatch", cn3: "CNBatch", tar_ei: Tensor) -> CNS
             raise NotImplementedError("cn6 takes the handles returned by ocn_amd.utils.adjoverlap")
     if not (cn1.adj1 is cn2.adj1 is cn3.adj1) or cn1.adj2 is not cn1.adj1:
         raise NotImplementedError("cn1/cn2/cn3 must come from adjoverlap(adj, adj|adj2|adj3, e) of one adjacency")
-    if ops.validate_indices and not (torch.equal(cn1.tarei, cn2.tarei) and torch.equal(cn1.tarei, cn3.tarei)
-                                     and torch.equal(cn1.tarei, tar_ei)):
+    if ops.validate_indices and not (_same_edges(cn1.tarei, cn2.tarei) and _same_edges(cn1.tarei, cn3.tarei)
+                                     and _same_edges(cn1.tarei, tar_ei)):
         raise NotImplementedError("cn1, cn2, cn3 and tar_ei must be built from the same candidate edges")
     return CNState3(cn1.adj1, cn2.adj2, cn3.adj2, cn1.tarei)
 
@@ -220,7 +230,7 @@ def fuse(cn1: CNBatch, cn2: CNBatch, tar_ei: Tensor, ws: Optional[dict] = None) 
         raise NotImplementedError("cn1 and cn2 must select their source rows from the same adjacency")
     if cn1.tarei.shape != cn2.tarei.shape or cn1.tarei.shape != tar_ei.shape:
         raise ValueError("cn1, cn2 and tar_ei describe different numbers of candidate edges")
-    if ops.validate_indices and not (torch.equal(cn1.tarei, cn2.tarei) and torch.equal(cn1.tarei, tar_ei)):
+    if ops.validate_indices and not (_same_edges(cn1.tarei, cn2.tarei) and _same_edges(cn1.tarei, tar_ei)):
         raise NotImplementedError("cn1, cn2 and tar_ei must be built from the same candidate edges")
     if cn1.mode == "walk1" and cn2.mode == "walk2":
         return CNState(cn1.adj1, None, None, cn1.tarei, walk=True, ws=ws)

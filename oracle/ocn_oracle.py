@@ -49,9 +49,15 @@ class SpM:
         return int(self.row.numel())
 
     def rowptr(self) -> Tensor:
-        cnt = torch.bincount(self.row, minlength=self.n_rows)
-        out = torch.zeros(self.n_rows + 1, dtype=torch.long)
-        torch.cumsum(cnt, 0, out=out[1:])
+        """CSR row pointer, cached on first use as torch_sparse's SparseStorage caches its ``_rowptr``
+        (the reference's ``adj[idx]`` at utils.py:256-257 therefore pays the bincount once per adjacency,
+        not once per batch)."""
+        out = self.__dict__.get("_rowptr_cache")
+        if out is None:
+            cnt = torch.bincount(self.row, minlength=self.n_rows)
+            out = torch.zeros(self.n_rows + 1, dtype=torch.long)
+            torch.cumsum(cnt, 0, out=out[1:])
+            self.__dict__["_rowptr_cache"] = out
         return out
 
     def rowcount(self) -> Tensor:

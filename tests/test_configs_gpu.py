@@ -28,13 +28,13 @@ def _sd(m):
     return {k: v.detach().clone() for k, v in m.state_dict().items()}
 
 
-# name, scale, encoder class, conv, layers, H, predictor, route, B, ln, res, jk, use ids, sum
+# name, scale, encoder class, conv, layers, H, predictor, route, B, ln, res, jk, use ids, sum, lnnn
 CONFIGS = [
-    ("cora", 1.0, "GCN", "puregcn", 1, 256, "cn5", "adj2", 1152, True, False, True, False, 0.0),      # README.md:27
-    ("collab", 0.05, "GCN", "gin", 1, 256, "cn5", "adj2", 4096, True, False, True, False, 0.0),      # README.md:42
-    ("ppa", 0.01, "GCN2", "gcn", 1, 64, "cn5", "walk", 2048, True, False, True, True, 0.0),          # README.md:47
-    ("citation2", 0.002, "GCN3", "gcn", 5, 32, "cn7", "walk", 2048, True, True, True, False, 1.0),   # README.md:92
-    ("ddi", 1.0, "GCN", "puregcn", 3, 64, "cn7", "block", 512, False, True, False, True, 2.74),      # README.md:98
+    ("cora", 1.0, "GCN", "puregcn", 1, 256, "cn5", "adj2", 1152, True, False, True, False, 0.0, True),      # README.md:27
+    ("collab", 0.05, "GCN", "gin", 1, 256, "cn5", "adj2", 4096, True, False, True, False, 0.0, True),      # README.md:42
+    ("ppa", 0.01, "GCN2", "gcn", 1, 64, "cn5", "walk", 2048, True, False, True, True, 0.0, True),          # README.md:47
+    ("citation2", 0.002, "GCN3", "gcn", 5, 32, "cn7", "walk", 2048, True, True, True, False, 1.0, False),  # README.md:92 (no --lnnn)
+    ("ddi", 1.0, "GCN", "puregcn", 3, 64, "cn7", "block", 512, False, True, False, True, 2.74, True),      # README.md:98
 ]
 
 
@@ -43,14 +43,19 @@ def test_baseline_config_end_to_end(hiplib, cfg):
     import ocn_amd.model as M
     from ocn_amd.sparse import SparseTensor
     from ocn_amd.utils import adjoverlap, get_cn1_cn2, sparse_tensor_multiply
-    name, scale, enc_cls, conv, L, H, pname, route, B, ln, res, jk, ids, sum_fill = cfg
+    from functools import partial
+    name, scale, enc_cls, conv, L, H, pname, route, B, ln, res, jk, ids, sum_fill, lnnn = cfg
     n, shape, oadj, adj = _graph(name, scale)
     torch.manual_seed(1)
     max_x = n if ids else -1
     fin = H if ids else (shape["feat"] or H)
     x = torch.arange(n) if ids else torch.randn(n, fin)
     enc = getattr(M, enc_cls)(fin, H, H, L, 0.1, ln, res, max_x, conv, jk, 0.0, xdropout=0.3, taildropout=0.2).eval()
-    pred = M.predictor_dict[pname](H, H, 1, 3, 0.05, 0.1, True, use_xlin=True, tailact=True, beta=0.33).eval()
+    # built as the drivers build it (NeighborOverlap_large.py:272-276,297-298): for cn5 / cn7 only cndeg is
+    # forwarded, so use_xlin / tailact / beta of the README commands never reach the constructor
+    pred = partial(M.predictor_dict[pname], cndeg=-1)(H, H, 1, 3, 0.05, 0.1, lnnn).eval()
+    with torch.no_grad():
+        pred.beta.fill_(0.33)
     args = SimpleNamespace(sum=sum_fill, adj2byblock=route == "block")
     e = sample_edges(oadj.row, oadj.col, n, B, seed=3)
 
@@ -64,7 +69,7 @@ def test_baseline_config_end_to_end(hiplib, cfg):
         oadj2 = O.adj2_by_block(oadj, 1024) if route == "block" else O.adj2_sparse(oadj)
         c1, c2 = O.adjoverlap(oadj, oadj, e), O.adjoverlap(oadj, oadj2, e)
     fwd = O.cn5_forward if pname == "cn5" else (lambda *a, **k: O.cn7_forward(*a[:5], sum_fill, *a[5:], **k))
-    ref = fwd(_sd(pred), h_ref, c1, c2, e, True, True)
+    ref = fwd(_sd(pred), h_ref, c1, c2, e, lnnn, False)
 
     # product, written the way the reference drivers call it
     with torch.no_grad():
