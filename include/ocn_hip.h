@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define OCN_ABI_VERSION 1
+#define OCN_ABI_VERSION 2
 #define OCN_EINVAL (-1)   /* null pointer / negative size / unsupported combination */
 #define OCN_ECAP   (-2)   /* reported through the device status word: flags capacity too small */
 
@@ -145,8 +145,34 @@ int ocn_walk_rev_offsets(const int64_t* rowptrA, const int64_t* nds, const int64
  * cn7 (model.py:3114-3126, 3186-3209): w1 = 1/S1, `sum_fill` where S1 < 2; cn2 raw ->
  * {w1, 0, 1, 0}. */
 int ocn_cn_weights_cn5(uint64_t* hist, int64_t N, const float* innerprod, int32_t* scalars,
-                       int32_t valued, void* stream);
+                       int32_t valued, const float* s2_exact /* or NULL: closed form from the counts */, void* stream);
 int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream);
+
+/* scalars[0] (zero before the first call of a batch; idempotent afterwards) = the batch's scale statistic of
+ * model.py:2370-2375: 0 = empty union, -1 = no column with S1 >= 2, else min{S1 >= 2} - INT_MAX - 1. */
+int ocn_cn5_column_stats(const uint64_t* hist, int64_t N, int32_t* scalars, void* stream);
+
+/* Order-exact column sums for a non-zero `innerprod` (every trained checkpoint).  The reference forms
+ * S2[c] = sum_e v[e,c], v = cn2 - nip*ncn1 on the union pattern, with index_add_ over the coalesced COO
+ * (model.py:2405-2406): one fp32 add per entry, in ascending batch-row order; where colsum(cn2) ~ nip the
+ * result depends on that order.  This entry transposes the union pattern of the batch into
+ * per-column lists of flag positions (count -> scan -> fill -> per-column sort: positions ascend with the batch
+ * row) and adds each column's values sequentially in fp32: s2[c] is bit for bit the reference's sum (before its
+ * `== 0 -> 1` fix-up); pass it to ocn_cn_weights_cn5 / _cn6 as s2_exact.  Must run BEFORE the weights entry
+ * (hist still holds the counts).  cn6 (flagsB = the cn3 flags of the (A, A^3) pass, s3 != NULL): additionally
+ * s3[c] = column sums of cn3 - nip*ncn1 - nip*ncn2' over the three-way union (model.py:2895-2913).
+ * wc: walk counts of the valued route or NULL.  flags_cap < 2^32.  scalars as for ocn_cn5_column_stats.
+ * s2_init (or NULL = zeros; cn5 only): the running sums of the EARLIER rows of an edge-sharded batch — rank r of
+ * ocn_amd/dist.py continues the chains rank r-1 left off (the global batch's rows ascend with the rank), so
+ * the last rank ends with the single-device sums; hist must then hold the all-reduced (global) counts, the
+ * entry counts of this shard are taken from the flags.
+ * workspace: ocn_cn_colsum_workspace_bytes(N, flags_cap) bytes of device scratch. */
+int64_t ocn_cn_colsum_workspace_bytes(int64_t N, int64_t flags_cap);
+int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, int64_t B,
+                        const int64_t* off, const uint8_t* flagsA, const uint8_t* flagsB /* or NULL */,
+                        const int32_t* wc /* or NULL */, int64_t flags_cap, const uint64_t* hist /* [N][2], counts */,
+                        int64_t N, const float* innerprod, int32_t* scalars, const float* s2_init /* [N] or NULL */,
+                        float* s2 /* [N] */, float* s3 /* [N], iff flagsB */, void* workspace, void* stream);
 
 /* The pooling: spmm_add(ncn1, x), spmm_add(ncn2, x) and x[i]*x[j] (model.py:2426-2429,
  * 3213-3216) in one pass.  xcn1[e] = sum_{k in cn1_e} w1[k] h[k]; xcn2[e] = sum over the
@@ -176,7 +202,8 @@ int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA,
  *   ocn_cn_gather3: xcn1, xcn2, xcn3 = spmm_add of the three normalised matrices (:2712-2713, :2933),
  *     xij = x_i * x_j.  H in {16, 32, 64, 128, 256, 512}. */
 int ocn_cn_weights_cn6(uint64_t* histA, uint64_t* histB, int64_t N, const float* innerprod, int32_t* scalars,
-                       float* nip_out, void* stream);
+                       float* nip_out, const float* s2_exact /* or NULL */, const float* s3_exact /* or NULL */,
+                       void* stream);
 int ocn_cn_gather3(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
                    const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flagsA,
                    const uint8_t* flagsB, const float* weightsA, const float* weightsB, const float* nip,

@@ -19,6 +19,7 @@ INCLUDE = os.path.join(_ROOT, "include")
 
 # name -> (restype, argtypes); must list every symbol include/ocn_hip.h declares
 _P = c_void_p
+ABI_VERSION = 2
 SIGNATURES = {
     "ocn_abi_version": (c_int32, []),
     "ocn_scan_workspace_bytes": (c_int64, [c_int64]),
@@ -36,11 +37,14 @@ SIGNATURES = {
                                     _P, _P]),
     "ocn_neighbor_degree_sum": (c_int32, [_P, _P, c_int64, _P, _P]),
     "ocn_walk_rev_offsets": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
-    "ocn_cn_weights_cn5": (c_int32, [_P, c_int64, _P, _P, c_int32, _P]),
+    "ocn_cn_weights_cn5": (c_int32, [_P, c_int64, _P, _P, c_int32, _P, _P]),
+    "ocn_cn5_column_stats": (c_int32, [_P, c_int64, _P, _P]),
+    "ocn_cn_colsum_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "ocn_cn_colsum_exact": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "ocn_cn_weights_cn7": (c_int32, [_P, c_int64, c_float, _P]),
     "ocn_cn_gather": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P, _P,
                                 _P, _P]),
-    "ocn_cn_weights_cn6": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P]),
+    "ocn_cn_weights_cn6": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "ocn_cn_gather3": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),
     "ocn_cn_gather_backward": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),
     "ocn_spmm_csr": (c_int32, [_P, _P, _P, c_int64, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
@@ -115,7 +119,7 @@ def lib() -> ctypes.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError if the symbol is not exported
             fn.restype, fn.argtypes = res, args
-        if l.ocn_abi_version() != 1:
+        if l.ocn_abi_version() != ABI_VERSION:
             raise OcnHipError("libocn_hip.so ABI version mismatch")
         _lib = l
     return _lib

@@ -2,15 +2,6 @@
 // (K2) and embedding pooling (K3).  See include/ocn_hip.h for the reference call sites.
 #include "common.h"
 
-typedef unsigned long long u64;
-
-// hist[c] = {packed, walks}: packed = n1 | n2 << 21 | n_union << 42 (one 64-bit atomic per CN entry
-// instead of three 32-bit ones), walks = sum of the walk counts of column c (valued cn2 only).
-#define HF_BITS 21
-#define HF_MASK ((1ull << HF_BITS) - 1ull)
-__device__ __forceinline__ int hf_n1(u64 w) { return (int)(w & HF_MASK); }
-__device__ __forceinline__ int hf_n2(u64 w) { return (int)((w >> HF_BITS) & HF_MASK); }
-__device__ __forceinline__ int hf_nu(u64 w) { return (int)((w >> (2 * HF_BITS)) & HF_MASK); }
 
 // ---------------------------------------------------------------------------------------------
 // sorted-list membership
@@ -502,15 +493,9 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn5_column_stats(const u64* __restr
 __global__ __launch_bounds__(OCN_BLOCK) void cn5_column_weights(u64* __restrict__ hist, i64 N,
                                                                 const float* __restrict__ innerprod,
                                                                 const int32_t* __restrict__ scalars,
-                                                                int valued) {
+                                                                int valued, const float* __restrict__ s2_exact) {
   // model.py:2370-2376: scale = max |ncn1| over the union-aligned vector (1.0 if it is empty)
-  const int sc = scalars[0];
-  float scale;
-  if (sc == 0) scale = 1.0f;                                        // empty union vector
-  else if (sc == -1) scale = 0.0f;                                  // only singleton columns: every ncn1 value is 0
-  else scale = 1.0f / (float)(sc + 0x7fffffff + 1);                 // largest 1/S1 among columns with S1 >= 2
-  const float ip = innerprod[0];
-  const float nip = scale > 0.0f ? ip / scale : ip;
+  const float nip = cn5_nip(scalars[0], innerprod[0]);
   float4* wout = reinterpret_cast<float4*>(hist);
   for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (i64)gridDim.x * blockDim.x) {
     const u64 pk = hist[2 * c];
@@ -519,20 +504,27 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn5_column_weights(u64* __restrict_
     const int n1 = hf_n1(pk), n2 = hf_n2(pk), nb = n1 + n2 - hf_nu(pk);
     const float inv1 = n1 >= 2 ? 1.0f / (float)n1 : 0.0f;              // :2263-2266 (Q2)
     const float t = __fmul_rn(nip, inv1);                              // nip * ncn1 value
-    // :2405-2406 column sum of v = cn2 − nip·ncn1 over the union pattern.  The reference adds the
-    // entries one by one in fp32 (edge order); here the distinct values are combined by their
-    // integer multiplicities in fp64 and rounded once.  Exact whenever nip == 0 (S2 = colsum(cn2)).
-    double s2d;
-    if (!valued) {
-      const float v_both = __fsub_rn(1.0f, t);                         // :2380-2384
-      const float v_only2 = __fsub_rn(1.0f, __fmul_rn(nip, 0.0f));
-      const float v_only1 = __fsub_rn(0.0f, t);
-      s2d = (double)(n2 - nb) * (double)v_only2 + (double)nb * (double)v_both +
-            (double)(n1 - nb) * (double)v_only1;
+    // :2405-2406 column sum of v = cn2 − nip·ncn1 over the union pattern.  The reference adds the entries one by
+    // one in fp32, in ascending batch-row order (index_add_ over the coalesced COO): s2_exact holds exactly that
+    // sum (ocn_cn_colsum_exact) whenever nip != 0.  For nip == 0 every v is an integer (1.0, or the walk count),
+    // the sequential fp32 sum is the integer count itself as long as it stays below 2^24, and the closed form
+    // below is that same number.
+    float S2;
+    if (s2_exact) {
+      S2 = s2_exact[c];
     } else {
-      s2d = (double)walks - (double)n1 * (double)t;
+      double s2d;
+      if (!valued) {
+        const float v_both = __fsub_rn(1.0f, t);                         // :2380-2384
+        const float v_only2 = __fsub_rn(1.0f, __fmul_rn(nip, 0.0f));
+        const float v_only1 = __fsub_rn(0.0f, t);
+        s2d = (double)(n2 - nb) * (double)v_only2 + (double)nb * (double)v_both +
+              (double)(n1 - nb) * (double)v_only1;
+      } else {
+        s2d = (double)walks - (double)n1 * (double)t;
+      }
+      S2 = (float)s2d;
     }
-    float S2 = (float)s2d;
     if (S2 == 0.0f) S2 = 1.0f;                                         // :2409
     wout[c] = make_float4(inv1, t, 1.0f / S2, 0.0f);                   // :2410-2413
   }
@@ -547,14 +539,10 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn5_column_weights(u64* __restrict_
 __global__ __launch_bounds__(OCN_BLOCK) void cn6_column_weights(u64* __restrict__ histA, u64* __restrict__ histB,
                                                                 i64 N, const float* __restrict__ innerprod,
                                                                 const int32_t* __restrict__ scalars,
-                                                                float* __restrict__ nip_out) {
-  const int sc = scalars[0];
-  float scale;
-  if (sc == 0) scale = 1.0f;
-  else if (sc == -1) scale = 0.0f;
-  else scale = 1.0f / (float)(sc + 0x7fffffff + 1);
-  const float ip = innerprod[0];
-  const float nip = scale > 0.0f ? ip / scale : ip;
+                                                                float* __restrict__ nip_out,
+                                                                const float* __restrict__ s2_exact,
+                                                                const float* __restrict__ s3_exact) {
+  const float nip = cn5_nip(scalars[0], innerprod[0]);
   if (blockIdx.x == 0 && threadIdx.x == 0) nip_out[0] = nip;
   float4* wa = reinterpret_cast<float4*>(histA);
   float4* wb = reinterpret_cast<float4*>(histB);
@@ -565,14 +553,20 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn6_column_weights(u64* __restrict_
     const float inv1 = n1 >= 2 ? 1.0f / (float)n1 : 0.0f;
     const float t = __fmul_rn(nip, inv1);
     const float v_both = __fsub_rn(1.0f, t), v_only2 = __fsub_rn(1.0f, __fmul_rn(nip, 0.0f)), v_only1 = __fsub_rn(0.0f, t);
-    float S2 = (float)((double)(n2 - nb) * (double)v_only2 + (double)nb * (double)v_both +
-                       (double)(n1 - nb) * (double)v_only1);
+    float S2 = s2_exact ? s2_exact[c]
+                        : (float)((double)(n2 - nb) * (double)v_only2 + (double)nb * (double)v_both +
+                                  (double)(n1 - nb) * (double)v_only1);
     if (S2 == 0.0f) S2 = 1.0f;
     const float inv2 = 1.0f / S2;
-    // column sum of the normalised cn2' values (1 up to rounding, or 0)
-    const double s2n = (double)(n2 - nb) * (double)__fmul_rn(v_only2, inv2) + (double)nb * (double)__fmul_rn(v_both, inv2) +
-                       (double)(n1 - nb) * (double)__fmul_rn(v_only1, inv2);
-    float S3 = (float)((double)n3 - (double)n1 * (double)t - (double)nip * s2n);
+    float S3;
+    if (s3_exact) {
+      S3 = s3_exact[c];
+    } else {
+      // column sum of the normalised cn2' values (1 up to rounding, or 0)
+      const double s2n = (double)(n2 - nb) * (double)__fmul_rn(v_only2, inv2) + (double)nb * (double)__fmul_rn(v_both, inv2) +
+                         (double)(n1 - nb) * (double)__fmul_rn(v_only1, inv2);
+      S3 = (float)((double)n3 - (double)n1 * (double)t - (double)nip * s2n);
+    }
     if (S3 == 0.0f) S3 = 1.0f;
     wa[c] = make_float4(inv1, t, inv2, 0.0f);
     wb[c] = make_float4(1.0f / S3, 0.0f, 0.0f, 0.0f);
@@ -1234,8 +1228,17 @@ int ocn_neighbor_degree_sum(const int64_t* rowptr, const int32_t* col, int64_t n
 
 int32_t ocn_walk_chunk(void) { return WALK_CHUNK; }
 
+int ocn_cn5_column_stats(const uint64_t* hist, int64_t N, int32_t* scalars, void* stream) {
+  if (N < 0 || (N > 0 && (!hist || !scalars))) return OCN_EINVAL;
+  if (N == 0) return 0;
+  const int grid = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 512);
+  hipLaunchKernelGGL(cn5_column_stats, dim3(grid), dim3(OCN_BLOCK), 0, (hipStream_t)stream, (const u64*)hist, (i64)N,
+                     scalars);
+  return launch_status();
+}
+
 int ocn_cn_weights_cn5(uint64_t* hist, int64_t N, const float* innerprod, int32_t* scalars,
-                       int32_t valued, void* stream) {
+                       int32_t valued, const float* s2_exact, void* stream) {
   if (N < 0 || (N > 0 && (!hist || !innerprod || !scalars))) return OCN_EINVAL;
   if (N == 0) return 0;
   const int grid = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
@@ -1243,12 +1246,12 @@ int ocn_cn_weights_cn5(uint64_t* hist, int64_t N, const float* innerprod, int32_
   hipLaunchKernelGGL(cn5_column_stats, dim3(grid < 512 ? grid : 512), dim3(OCN_BLOCK), 0, st,
                      (const u64*)hist, (i64)N, scalars);
   hipLaunchKernelGGL(cn5_column_weights, dim3(grid), dim3(OCN_BLOCK), 0, st, (u64*)hist, (i64)N,
-                     innerprod, (const int32_t*)scalars, (int)valued);
+                     innerprod, (const int32_t*)scalars, (int)valued, s2_exact);
   return launch_status();
 }
 
 int ocn_cn_weights_cn6(uint64_t* histA, uint64_t* histB, int64_t N, const float* innerprod, int32_t* scalars,
-                       float* nip_out, void* stream) {
+                       float* nip_out, const float* s2_exact, const float* s3_exact, void* stream) {
   if (N < 0 || (N > 0 && (!histA || !histB || !innerprod || !scalars || !nip_out))) return OCN_EINVAL;
   if (N == 0) return 0;
   const int grid = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
@@ -1256,7 +1259,7 @@ int ocn_cn_weights_cn6(uint64_t* histA, uint64_t* histB, int64_t N, const float*
   hipLaunchKernelGGL(cn5_column_stats, dim3(grid < 512 ? grid : 512), dim3(OCN_BLOCK), 0, st,
                      (const u64*)histA, (i64)N, scalars);
   hipLaunchKernelGGL(cn6_column_weights, dim3(grid), dim3(OCN_BLOCK), 0, st, (u64*)histA, (u64*)histB, (i64)N,
-                     innerprod, (const int32_t*)scalars, nip_out);
+                     innerprod, (const int32_t*)scalars, nip_out, s2_exact, s3_exact);
   return launch_status();
 }
 

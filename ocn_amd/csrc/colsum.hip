@@ -1,0 +1,281 @@
+// Order-exact column sums for cn5 / cn6 when the predictor's `innerprod` buffer is non-zero (every trained
+// checkpoint).  The reference sums the orthogonalised values v = cn2 - nip * ncn1 of a column entry by entry in
+// fp32 with index_add_ over the coalesced COO pattern (model.py:2405-2406; cn6 :2912-2913), i.e. in ascending
+// batch-row order; where colsum(cn2) ~ nip the result depends on that order.  Here the union pattern is
+// transposed into per-column entry lists — count (the histogram's n_union field, or an atomic count when a
+// second flag array joins) -> scan -> fill -> sort by flag position (positions ascend with the batch row) — and
+// one lane chain adds each column's values in that order, every product / difference rounded separately.
+#include "common.h"
+
+#define CS_WAVE_MAX 64          /* columns with at most this many entries: one wave each */
+#ifndef OCN_X_CS_LDS
+#define OCN_X_CS_LDS 8192       /* longer columns up to this many entries are sorted in LDS, beyond in place in memory */
+#endif
+#define CS_CHUNK 2048           /* values staged in LDS per accumulation round of a long column */
+
+// ---------------------------------------------------------------------------------------------
+// entry lists
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OCN_BLOCK) void colsum_nu_kernel(const u64* __restrict__ hist, i64 N,
+                                                              int32_t* __restrict__ counts) {
+  for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (i64)gridDim.x * blockDim.x)
+    counts[c] = hf_nu(hist[2 * c]);
+}
+
+__global__ __launch_bounds__(OCN_BLOCK) void colsum_zero_kernel(int32_t* __restrict__ p, i64 n) {
+  for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (i64)gridDim.x * blockDim.x) p[q] = 0;
+}
+
+// One wave per batch row.  FILL = false: counts[k] += 1 per union entry; FILL = true: the entry's flag position
+// goes to the next free slot of its column (cursor zero on entry).
+template <bool FILL>
+__global__ __launch_bounds__(OCN_BLOCK) void colsum_entries_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA, const i64* __restrict__ src, i64 B,
+    const i64* __restrict__ off, const uint8_t* __restrict__ flagsA, const uint8_t* __restrict__ flagsB, i64 cap,
+    const i64* __restrict__ col_off, int32_t* __restrict__ cursor, uint32_t* __restrict__ entries) {
+  const int lane = threadIdx.x & 63;
+  for (i64 e = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6); e < B; e += (i64)gridDim.x * OCN_WPB) {
+    const i64 i = src[e];
+    const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0, base = off[e];
+    if (base + da > cap) continue;                       // row beyond the flag capacity: nothing was written for it
+    for (i64 p = lane; p < da; p += OCN_WAVE) {
+      unsigned f = flagsA[base + p];
+      if (flagsB) f |= (unsigned)(flagsB[base + p] & OCN_F_CN1) << 2;
+      if (!f) continue;
+      const int32_t k = colA[a0 + p];
+      const int slot = atomicAdd(cursor + k, 1);
+      if (FILL) entries[col_off[k] + slot] = (uint32_t)(base + p);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// values and chains
+// ---------------------------------------------------------------------------------------------
+struct ColCtx {
+  const uint8_t* flagsA;
+  const uint8_t* flagsB;
+  const int32_t* wc;
+  float nip;
+};
+
+// v2 of the entry at flag position p in a column with t = nip * inv1 (model.py:2380-2384); in2 = the entry
+// belongs to the stage-1 union (cn1 or cn2), a3 = its cn3 value (cn6)
+__device__ __forceinline__ float entry_v2(const ColCtx& cx, uint32_t p, float t, bool& in2, float& a3, float& tt) {
+  const unsigned fa = cx.flagsA[p];
+  const float c = (fa & OCN_F_CN2) ? (cx.wc ? (float)cx.wc[p] : 1.0f) : 0.0f;
+  tt = (fa & OCN_F_CN1) ? t : 0.0f;
+  in2 = fa != 0;
+  a3 = (cx.flagsB && (cx.flagsB[p] & OCN_F_CN1)) ? 1.0f : 0.0f;
+  return __fsub_rn(c, tt);
+}
+
+// acc + v[0] + v[1] + ... + v[cnt-1] in that order, v[r] held by lane r (wave-uniform result)
+__device__ __forceinline__ float chain_add(float acc, float v, int cnt) {
+  const int vi = __builtin_bit_cast(int, v);
+  for (int r = 0; r < cnt; ++r) acc = __fadd_rn(acc, __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, r)));
+  return acc;
+}
+
+__device__ __forceinline__ float col_t(const u64* hist, i64 c, float nip) {
+  const int n1 = hf_n1(hist[2 * c]);
+  const float inv1 = n1 >= 2 ? 1.0f / (float)n1 : 0.0f;               // model.py:2263-2266
+  return __fmul_rn(nip, inv1);
+}
+
+// Columns with <= 64 entries: one wave each (rank sort in registers, ds_permute into rank order, lane chain);
+// longer columns are appended to long_list for colsum_long_kernel.
+__global__ __launch_bounds__(OCN_BLOCK) void colsum_short_kernel(
+    const u64* __restrict__ hist, i64 N, const i64* __restrict__ col_off, const uint32_t* __restrict__ entries,
+    ColCtx cx, const float* __restrict__ innerprod, const int32_t* __restrict__ scalars,
+    float* __restrict__ s2, float* __restrict__ s3, int32_t* __restrict__ long_list, int32_t* __restrict__ n_long,
+    const float* __restrict__ s2_init) {
+  const int lane = threadIdx.x & 63;
+  cx.nip = cn5_nip(scalars[0], innerprod[0]);
+  for (i64 c = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6); c < N; c += (i64)gridDim.x * OCN_WPB) {
+    const i64 b = col_off[c];
+    const int n = (int)(col_off[c + 1] - b);
+    if (n == 0) {                                        // no entry here: an earlier shard's partial sum passes through
+      if (s2_init && lane == 0) s2[c] = s2_init[c];
+      continue;
+    }
+    if (n > CS_WAVE_MAX) {
+      if (lane == 0) long_list[atomicAdd(n_long, 1)] = (int32_t)c;
+      continue;
+    }
+    const uint32_t p = lane < n ? entries[b + lane] : 0xffffffffu;
+    int rank = 0;
+    for (int m = 0; m < n; ++m) rank += (uint32_t)__builtin_amdgcn_readlane((int)p, m) < p;
+    const float t = col_t(hist, c, cx.nip);
+    bool in2 = false;
+    float a3 = 0.f, tt = 0.f, v2 = 0.f;
+    if (lane < n) v2 = entry_v2(cx, p, t, in2, a3, tt);
+    // lane l pushes its values to lane rank_l: afterwards lane r holds the r-th entry in ascending position order
+    const int dst = (lane < n ? rank : lane) << 2;
+    const float v2s = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dst, __builtin_bit_cast(int, in2 ? v2 : 0.0f)));
+    float S2 = chain_add(s2_init ? s2_init[c] : 0.0f, v2s, n);   // entries outside the stage-1 union add +0.0: no effect
+    s2[c] = S2;
+    if (s3) {
+      if (S2 == 0.0f) S2 = 1.0f;                         // model.py:2409 / :2705
+      const float inv2 = 1.0f / S2;
+      // v3 = cn3 - nip * ncn1 - nip * ncn2' (:2895-2899), ncn2' = v2 / S2 on the stage-1 union, 0 elsewhere
+      const float a2n = in2 ? __fmul_rn(v2, inv2) : 0.0f;
+      const float v3 = __fsub_rn(__fsub_rn(a3, tt), __fmul_rn(cx.nip, a2n));
+      const float v3s = __builtin_bit_cast(float, __builtin_amdgcn_ds_permute(dst, __builtin_bit_cast(int, lane < n ? v3 : 0.0f)));
+      s3[c] = chain_add(0.0f, v3s, n);
+    }
+  }
+}
+
+// In-place sort of a[0..n) (LDS or global), any n: the bitonic network in its all-ascending form (first step of
+// a merge mirrors, the rest are strides; every compare-exchange leaves the minimum at the lower index), so
+// partners beyond n behave as +inf and are simply skipped.
+template <typename P>
+__device__ __forceinline__ void wg_sort(P a, int n) {
+  int pow2 = 1;
+  while (pow2 < n) pow2 <<= 1;
+  for (int k = 2; k <= pow2; k <<= 1) {
+    const int hk = k >> 1;
+    for (int i = threadIdx.x; i < (pow2 >> 1); i += blockDim.x) {
+      const int blk = i / hk, o = i - blk * hk;
+      const int lo = blk * k + o, hi = blk * k + k - 1 - o;
+      if (hi < n) { const uint32_t x = a[lo], y = a[hi]; if (y < x) { a[lo] = y; a[hi] = x; } }
+    }
+    __syncthreads();
+    for (int j = hk >> 1; j >= 1; j >>= 1) {
+      for (int i = threadIdx.x; i < (pow2 >> 1); i += blockDim.x) {
+        const int blk = i / j, o = i - blk * j;
+        const int lo = blk * 2 * j + o, hi = lo + j;
+        if (hi < n) { const uint32_t x = a[lo], y = a[hi]; if (y < x) { a[lo] = y; a[hi] = x; } }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// One workgroup per long column (ticket-drawn from long_list): sort its entry positions, then wave 0 adds the
+// values in that order, CS_CHUNK at a time through LDS.
+__global__ __launch_bounds__(OCN_BLOCK) void colsum_long_kernel(
+    const u64* __restrict__ hist, const i64* __restrict__ col_off, uint32_t* __restrict__ entries,
+    ColCtx cx, const float* __restrict__ innerprod, const int32_t* __restrict__ scalars,
+    float* __restrict__ s2, float* __restrict__ s3, const int32_t* __restrict__ long_list,
+    const int32_t* __restrict__ n_long, int32_t* __restrict__ ticket, const float* __restrict__ s2_init) {
+  __shared__ uint32_t s_key[OCN_X_CS_LDS];
+  __shared__ float s_val[CS_CHUNK];
+  __shared__ int s_item;
+  __shared__ float s_inv2;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  cx.nip = cn5_nip(scalars[0], innerprod[0]);
+  const int total = n_long[0];
+  for (;;) {
+    if (threadIdx.x == 0) s_item = atomicAdd(ticket, 1);
+    __syncthreads();
+    const int item = s_item;
+    if (item >= total) break;                            // every wave reaches this: the grid drains
+    const i64 c = long_list[item];
+    const i64 b = col_off[c];
+    const int n = (int)(col_off[c + 1] - b);
+    uint32_t* keys = entries + b;
+    const bool in_lds = n <= OCN_X_CS_LDS;
+    if (in_lds) {
+      for (int q = threadIdx.x; q < n; q += OCN_BLOCK) s_key[q] = keys[q];
+      __syncthreads();
+      wg_sort(&s_key[0], n);
+    } else {
+      wg_sort(keys, n);
+    }
+    const float t = col_t(hist, c, cx.nip);
+    for (int pass = 0; pass < (s3 ? 2 : 1); ++pass) {
+      float acc = (pass == 0 && s2_init) ? s2_init[c] : 0.0f;
+      const float inv2 = pass ? s_inv2 : 0.0f;
+      for (int q0 = 0; q0 < n; q0 += CS_CHUNK) {
+        const int m = n - q0 < CS_CHUNK ? n - q0 : CS_CHUNK;
+        for (int q = threadIdx.x; q < m; q += OCN_BLOCK) {
+          const uint32_t p = in_lds ? s_key[q0 + q] : keys[q0 + q];
+          bool in2;
+          float a3, tt;
+          const float v2 = entry_v2(cx, p, t, in2, a3, tt);
+          float v = in2 ? v2 : 0.0f;
+          if (pass) v = __fsub_rn(__fsub_rn(a3, tt), __fmul_rn(cx.nip, in2 ? __fmul_rn(v2, inv2) : 0.0f));
+          s_val[q] = v;
+        }
+        __syncthreads();
+        if (w == 0) {
+          for (int r0 = 0; r0 < m; r0 += OCN_WAVE) {
+            const float v = r0 + lane < m ? s_val[r0 + lane] : 0.0f;
+            acc = chain_add(acc, v, m - r0 < OCN_WAVE ? m - r0 : OCN_WAVE);
+          }
+        }
+        __syncthreads();
+      }
+      if (threadIdx.x == 0) {
+        if (pass == 0) {
+          s2[c] = acc;
+          s_inv2 = 1.0f / (acc == 0.0f ? 1.0f : acc);
+        } else {
+          s3[c] = acc;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+extern "C" {
+
+int64_t ocn_cn_colsum_workspace_bytes(int64_t N, int64_t flags_cap) {
+  // col_off int64[N+1] | counts/cursor int32[N] | long_list int32[N] | tickets int32[4] | entries uint32[cap] | scan ws
+  const int64_t a = ((N + 1) * 8 + 15) / 16 * 16, b = (N * 4 + 15) / 16 * 16;
+  return a + 2 * b + 16 + (flags_cap * 4 + 15) / 16 * 16 + ocn_scan_workspace_bytes(N) + 64;
+}
+
+int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, int64_t B,
+                        const int64_t* off, const uint8_t* flagsA, const uint8_t* flagsB, const int32_t* wc,
+                        int64_t flags_cap, const uint64_t* hist, int64_t N, const float* innerprod, int32_t* scalars,
+                        const float* s2_init, float* s2, float* s3, void* workspace, void* stream) {
+  if (B < 0 || N < 0 || flags_cap < 0 || flags_cap > 0xfffffffell) return OCN_EINVAL;
+  if (N == 0) return 0;
+  if (!hist || !innerprod || !scalars || !s2 || !workspace) return OCN_EINVAL;
+  if (B > 0 && (!rowptrA || !src || !off || !flagsA)) return OCN_EINVAL;
+  if ((flagsB != nullptr) != (s3 != nullptr) || (flagsB && (wc || s2_init))) return OCN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  const int64_t a = ((N + 1) * 8 + 15) / 16 * 16, b = (N * 4 + 15) / 16 * 16;
+  i64* col_off = (i64*)ws;
+  int32_t* counts = (int32_t*)(ws + a);
+  int32_t* long_list = (int32_t*)(ws + a + b);
+  int32_t* tickets = (int32_t*)(ws + a + 2 * b);                    // [0] number of long columns, [1] work ticket
+  uint32_t* entries = (uint32_t*)(ws + a + 2 * b + 16);
+  void* scan_ws = (void*)(ws + a + 2 * b + 16 + (flags_cap * 4 + 15) / 16 * 16);
+  const int gridN = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
+  const int gridB = grid_for((B + OCN_WPB - 1) / OCN_WPB, 1 << 16);
+  int rc = ocn_cn5_column_stats(hist, N, scalars, stream);           // nip needs the batch's scale (idempotent)
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_zero_kernel, dim3(1), dim3(OCN_BLOCK), 0, st, tickets, (i64)4);
+  if (flagsB || s2_init) {        // cn6: the union is wider than histA's n_union; a shard: hist holds the GLOBAL counts
+    hipLaunchKernelGGL(colsum_zero_kernel, dim3(gridN), dim3(OCN_BLOCK), 0, st, counts, (i64)N);
+    if (B > 0)
+      hipLaunchKernelGGL((colsum_entries_kernel<false>), dim3(gridB), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA, colA,
+                         (const i64*)src, (i64)B, (const i64*)off, flagsA, flagsB, (i64)flags_cap,
+                         (const i64*)nullptr, counts, (uint32_t*)nullptr);
+  } else {
+    hipLaunchKernelGGL(colsum_nu_kernel, dim3(gridN), dim3(OCN_BLOCK), 0, st, (const u64*)hist, (i64)N, counts);
+  }
+  rc = ocn_scan_i32(counts, N, (int64_t*)col_off, scan_ws, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_zero_kernel, dim3(gridN), dim3(OCN_BLOCK), 0, st, counts, (i64)N);
+  if (B > 0)
+    hipLaunchKernelGGL((colsum_entries_kernel<true>), dim3(gridB), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA, colA,
+                       (const i64*)src, (i64)B, (const i64*)off, flagsA, flagsB, (i64)flags_cap, (const i64*)col_off,
+                       counts, entries);
+  ColCtx cx{flagsA, flagsB, wc, 0.0f};
+  hipLaunchKernelGGL(colsum_short_kernel, dim3(grid_for((N + OCN_WPB - 1) / OCN_WPB, 1 << 15)), dim3(OCN_BLOCK), 0, st,
+                     (const u64*)hist, (i64)N, (const i64*)col_off, (const uint32_t*)entries, cx, innerprod,
+                     (const int32_t*)scalars, s2, s3, long_list, tickets, s2_init);
+  hipLaunchKernelGGL(colsum_long_kernel, dim3(256 * 2), dim3(OCN_BLOCK), 0, st, (const u64*)hist, (const i64*)col_off,
+                     entries, cx, innerprod, (const int32_t*)scalars, s2, s3, (const int32_t*)long_list,
+                     (const int32_t*)tickets, tickets + 1, s2_init);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -9,6 +9,25 @@
 #define OCN_WPB (OCN_BLOCK / OCN_WAVE)
 
 typedef long long i64;
+typedef unsigned long long u64;
+
+// hist[c] = {packed, walks}: packed = n1 | n2 << 21 | n_union << 42 (one 64-bit atomic per CN entry
+// instead of three 32-bit ones), walks = sum of the walk counts of column c (valued cn2 only).
+#define HF_BITS 21
+#define HF_MASK ((1ull << HF_BITS) - 1ull)
+__device__ __forceinline__ int hf_n1(u64 w) { return (int)(w & HF_MASK); }
+__device__ __forceinline__ int hf_n2(u64 w) { return (int)((w >> HF_BITS) & HF_MASK); }
+__device__ __forceinline__ int hf_nu(u64 w) { return (int)((w >> (2 * HF_BITS)) & HF_MASK); }
+
+// cn5 / cn6: nip = innerprod / scale from the column statistics word (cn5_column_stats: 0 = no union entry,
+// -1 = union entries but no column with n1 >= 2, else min{n1 >= 2} - INT_MAX - 1); model.py:2370-2376
+__device__ __forceinline__ float cn5_nip(int sc, float ip) {
+  float scale;
+  if (sc == 0) scale = 1.0f;                                        // empty union vector
+  else if (sc == -1) scale = 0.0f;                                  // only singleton columns: every ncn1 value is 0
+  else scale = 1.0f / (float)(sc + 0x7fffffff + 1);                 // largest 1/S1 among columns with S1 >= 2
+  return scale > 0.0f ? ip / scale : ip;
+}
 
 static inline int launch_status() { return (int)hipGetLastError(); }
 

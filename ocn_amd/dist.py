@@ -5,8 +5,9 @@ for.  The adjacency, A², the embeddings and the weights are replicated; a candi
 into contiguous slices, one per rank.  Because the predictors normalise per column over the WHOLE
 batch (``cn.sum(dim=0)``, model.py:2261,3114), ranks exchange exactly one thing before pooling: the
 per-column histograms {n1, n2, n_union, walks} (packed int64, sum all-reduce — integer, so exact and
-order-independent; cn5's ``scale`` and S2 are functions of those counts and need no extra
-collective).  Scores come back with one all-gather.
+order-independent; cn5's ``scale`` and — for a fresh model, innerprod == 0 — S2 are functions of those counts
+and need no extra collective; with a trained innerprod S2 depends on the reference's entry order and is chained
+through the ranks, ``ring_colsum``).  Scores come back with one all-gather.
 """
 from __future__ import annotations
 
@@ -49,6 +50,34 @@ def allreduce_hist(hist: Tensor, group=None, valued: bool = True) -> Tensor:
         if not valued:
             hist[:, 0].copy_(buf)
     return hist
+
+
+def ring_colsum(run, n_cols: int, device, group=None) -> Tensor:
+    """Order-exact S2 of an edge-sharded cn5 batch (innerprod != 0).  The reference adds a column's entries in
+    ascending batch-row order (model.py:2405-2406) and the shards are contiguous row ranges, so the sum is a chain
+    through the ranks: rank 0 starts from zeros, every rank continues from its predecessor's running sums
+    (``run(init)`` = ocn_cn_colsum_exact with ``s2_init``), the last rank holds the single-device result and
+    broadcasts it.  One [N] fp32 vector per hop — serial in the world size by construction, which is the price of
+    the reference's summation order; a fresh model (innerprod == 0) never takes this path."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return run(None)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ranks = [dist.get_global_rank(group, r) if group is not None else r for r in range(world)]
+    host = dist.get_backend(group) == "gloo"
+    stage = torch.empty(n_cols, dtype=torch.float32, device="cpu" if host else device)
+    if rank == 0:
+        init = torch.zeros(n_cols, dtype=torch.float32, device=device)
+    else:
+        dist.recv(stage, src=ranks[rank - 1], group=group)
+        init = stage.to(device)
+    s2 = run(init)
+    if rank < world - 1:
+        dist.send(s2.cpu() if host else s2, dst=ranks[rank + 1], group=group)
+    out = s2.cpu() if host else s2
+    dist.broadcast(out, src=ranks[world - 1], group=group)
+    if host:
+        s2.copy_(out)
+    return s2
 
 
 def check_global_batch(total: int) -> None:

@@ -16,9 +16,13 @@ import torch
 import torch.nn as nn
 from torch import Tensor
 
+import os
+
 from . import ops
 from .sparse import SparseTensor
 from .utils import fuse
+
+_X_CAPTURE_QUERY = bool(os.environ.get("OCN_X_CAPTURE_QUERY"))   # tools/graph_fault_ab.py: the round-1 behaviour
 
 
 # ------------------------------------------------------------------------------------------
@@ -447,6 +451,7 @@ class _CNPredictorBase(nn.Module):
         if self._sharded:
             from .dist import allreduce_hist
             allreduce_hist(st.hist, self._shard_group, valued=st.walk)
+            st.sharded, st.shard_group = True, self._shard_group
             ops._mark("allreduce_hist")
         return st
 
@@ -478,8 +483,8 @@ class _CNPredictorBase(nn.Module):
         pr = getattr(self, "_skip_state", None)
         if pr is None:
             return True
-        if torch.cuda.is_current_stream_capturing():     # no event query while capturing: replay what was last decided
-            return pr["off"] == 0
+        if torch.cuda.is_current_stream_capturing() and not _X_CAPTURE_QUERY:   # no event query while capturing:
+            return pr["off"] == 0                                                # replay what was last decided
         if pr["pending"] is not None and pr["pending"].query():
             r = pr["host"]
             B = max(int(pr["B"]), 1)
@@ -759,7 +764,7 @@ class CNLinkPredictor3hopCNs(_CNPredictorBase):
             from .dist import allreduce_hist
             allreduce_hist(st.a.hist, self._shard_group, valued=False)
             allreduce_hist(st.b.hist, self._shard_group, valued=False)
-        wa, wb, nip = st.weights(self.innerprod)
+        wa, wb, nip = st.weights(self.innerprod, sharded=self._sharded)
         xcn1, xcn2, xcn3, xij = st.gather(wa, wb, nip, x.contiguous())
         with torch.no_grad():
             alpha = torch.sigmoid(self.alpha).cumprod(-1)

@@ -242,14 +242,67 @@ def neighbor_degree_sum(rowptr: Tensor, col: Tensor) -> Tensor:
     return out
 
 
+exact_colsum = True              # cn5 / cn6 with innerprod != 0: column sums in the reference's entry order (ocn_cn_colsum_exact)
+
+
+def _ip_nonzero(innerprod: Tensor) -> bool:
+    """Whether the ``innerprod`` buffer is non-zero, read back once per value: cached per live tensor object
+    (weak reference) and version counter, so an eval loop pays one host sync in total, not one per batch — and a
+    freed tensor's address being reused by another one cannot hit."""
+    import weakref
+    hit = _ip_cache.get("k")
+    if hit is None or hit[0]() is not innerprod or hit[1] != innerprod.data_ptr() or hit[2] != innerprod._version:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("innerprod changed since the last eager call: run one eager batch before capturing")
+        _ip_cache["k"] = (weakref.ref(innerprod), innerprod.data_ptr(), innerprod._version)
+        _ip_cache["v"] = bool(innerprod.detach().reshape(-1)[0].item() != 0.0)
+    return _ip_cache["v"]
+
+
+_ip_cache: dict = {}
+
+
+def colsum_wanted(innerprod: Tensor) -> bool:
+    """cn5 / cn6: is the second column normalisation to be summed in the reference's entry order?  Only a
+    non-zero ``innerprod`` makes the order matter (for 0 the closed form over the integer counts is exact)."""
+    return exact_colsum and _ip_nonzero(innerprod)
+
+
 @_on_device
-def cn_weights_cn5(hist: Tensor, innerprod: Tensor, valued: bool = False, wsd=None) -> Tensor:
-    """In place: packed int64 [N,2] histogram -> float32 [N,4] weights {w1, t, inv2, 0} (same storage)."""
+def cn_colsum_exact(rowptrA, colA, src, off, flagsA, flagsB, wc, hist: Tensor, innerprod: Tensor, scal: Tensor, wsd=None,
+                    s2_init: Optional[Tensor] = None):
+    """Order-exact S2 (and S3 with ``flagsB``) of the batch; ocn_hip.h: ocn_cn_colsum_exact.  ``scal``: the
+    batch's zeroed int32[4] statistics scratch (shared with the weights call).  Returns (s2, s3|None)."""
+    _req(hist, torch.int64, "hist", 2)
+    N, dev = hist.shape[0], hist.device
+    cap = flagsA.numel()
+    if cap >= (1 << 32) - 1:
+        raise NotImplementedError("order-exact column sums address flag positions with 32 bits")
+    ip = _req(innerprod.detach().reshape(1).to(torch.float32), torch.float32, "innerprod", 1)
+    if s2_init is not None and _req(s2_init, torch.float32, "s2_init", 1).numel() != N:
+        raise ValueError("s2_init must have one entry per column")
+    s2 = buf(wsd, "s2_exact", N, torch.float32, dev)
+    s3 = buf(wsd, "s3_exact", N, torch.float32, dev) if flagsB is not None else None
+    ws = buf(wsd, "colsum_ws", int(_lib.lib().ocn_cn_colsum_workspace_bytes(N, cap)) // 8 + 1, torch.int64, dev)
+    check(_lib.lib().ocn_cn_colsum_exact(ptr(rowptrA), ptr(colA), ptr(src), src.numel(), ptr(off), ptr(flagsA), ptr(flagsB),
+                                         ptr(wc), cap, ptr(hist), N, ptr(ip), ptr(scal), ptr(s2_init), ptr(s2), ptr(s3),
+                                         ptr(ws), stream_ptr()), "ocn_cn_colsum_exact")
+    _mark("cn_colsum")
+    return s2, s3
+
+
+@_on_device
+def cn_weights_cn5(hist: Tensor, innerprod: Tensor, valued: bool = False, wsd=None, s2_exact: Optional[Tensor] = None,
+                   scal: Optional[Tensor] = None) -> Tensor:
+    """In place: packed int64 [N,2] histogram -> float32 [N,4] weights {w1, t, inv2, 0} (same storage).
+    ``s2_exact``: the column sums of ``cn_colsum_exact`` (then ``scal`` is the statistics scratch that call
+    used); None: the closed form over the integer counts (exact for innerprod == 0)."""
     _req(hist, torch.int64, "hist", 2)
     ip = _req(innerprod.detach().reshape(1).to(torch.float32), torch.float32, "innerprod", 1)
-    scal = buf(wsd, "scal", 4, torch.int32, hist.device, zero=True)
-    check(_lib.lib().ocn_cn_weights_cn5(ptr(hist), hist.shape[0], ptr(ip), ptr(scal), int(valued), stream_ptr()),
-          "ocn_cn_weights_cn5")
+    if scal is None:
+        scal = buf(wsd, "scal", 4, torch.int32, hist.device, zero=True)
+    check(_lib.lib().ocn_cn_weights_cn5(ptr(hist), hist.shape[0], ptr(ip), ptr(scal), int(valued), ptr(s2_exact),
+                                        stream_ptr()), "ocn_cn_weights_cn5")
     _mark("cn_weights")
     return hist.view(torch.float32)
 
@@ -303,17 +356,22 @@ def class_order(cnt1: Tensor, cnt2: Optional[Tensor], order: Optional[Tensor], w
 
 
 @_on_device
-def cn_weights_cn6(histA: Tensor, histB: Tensor, innerprod: Tensor):
+def cn_weights_cn6(histA: Tensor, histB: Tensor, innerprod: Tensor, exact=None):
     """In place: histA -> float32 [N,4] {inv1, t, inv2, 0}, histB -> {1/S3, 0, 0, 0}; returns them and the
-    device scalar nip (ocn_hip.h: ocn_cn_weights_cn6)."""
+    device scalar nip (ocn_hip.h: ocn_cn_weights_cn6).  ``exact`` = (rowptrA, colA, src, off, flagsA, flagsB):
+    order-exact S2 / S3 for a non-zero ``innerprod``, as for cn5."""
     _req(histA, torch.int64, "histA", 2); _req(histB, torch.int64, "histB", 2)
     if histA.shape != histB.shape:
         raise ValueError("histA / histB shape mismatch")
     ip = _req(innerprod.detach().reshape(1).to(torch.float32), torch.float32, "innerprod", 1)
     scal = torch.zeros(4, dtype=torch.int32, device=histA.device)
     nip = torch.empty(1, dtype=torch.float32, device=histA.device)
+    s2 = s3 = None
+    if exact is not None and colsum_wanted(innerprod):
+        rowptrA, colA, src, off, flagsA, flagsB = exact
+        s2, s3 = cn_colsum_exact(rowptrA, colA, src, off, flagsA, flagsB, None, histA, innerprod, scal)
     check(_lib.lib().ocn_cn_weights_cn6(ptr(histA), ptr(histB), histA.shape[0], ptr(ip), ptr(scal), ptr(nip),
-                                        stream_ptr()), "ocn_cn_weights_cn6")
+                                        ptr(s2), ptr(s3), stream_ptr()), "ocn_cn_weights_cn6")
     _mark("cn_weights")
     return histA.view(torch.float32).view(-1, 4), histB.view(torch.float32).view(-1, 4), nip
 

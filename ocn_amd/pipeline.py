@@ -96,10 +96,6 @@ class GraphedScorer:
     def __init__(self, predictor, h: Tensor, adj, adj2, batch_size: int, args=None, route: str = "pattern"):
         if predictor.training:
             raise RuntimeError("GraphedScorer is the eval path; call predictor.eval() first")
-        if int(batch_size) >= ops.sort_edges_min_batch:
-            # validated for the small-batch regime only (where the host is the cost); a 65 536-edge capture
-            # ended in a GPU memory fault on MI355X and buys nothing: such a batch is GPU-bound
-            raise ValueError(f"GraphedScorer is for small batches (< {ops.sort_edges_min_batch} candidates)")
         self.pred, self.h, self.adj, self.adj2, self.args, self.route = predictor, h.contiguous(), adj, adj2, args, route
         self.B = int(batch_size)
         dev = h.device

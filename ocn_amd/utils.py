@@ -83,7 +83,18 @@ class CNState:
     def weights_cn5(self, innerprod: Tensor) -> Tensor:
         assert self._hist_live, "histogram already consumed"
         self._hist_live = False
-        return ops.cn_weights_cn5(self.hist, innerprod, valued=self.walk, wsd=self.ws)
+        s2 = scal = None
+        if ops.colsum_wanted(innerprod):
+            # innerprod != 0 (a trained checkpoint): S2 summed entry by entry in the reference's order
+            scal = ops.buf(self.ws, "scal", 4, torch.int32, self.hist.device, zero=True)
+            run = lambda init: ops.cn_colsum_exact(self.adj._rowptr, self.adj._col, self.src, self.off, self.flags, None,
+                                                   self.wc, self.hist, innerprod, scal, self.ws, s2_init=init)[0]
+            if getattr(self, "sharded", False):
+                from .dist import ring_colsum          # an edge shard continues the chains of the ranks before it
+                s2 = ring_colsum(run, self.hist.shape[0], self.hist.device, self.shard_group)
+            else:
+                s2 = run(None)
+        return ops.cn_weights_cn5(self.hist, innerprod, valued=self.walk, wsd=self.ws, s2_exact=s2, scal=scal)
 
     def weights_cn7(self, sum_fill: float) -> Tensor:
         assert self._hist_live, "histogram already consumed"
@@ -187,10 +198,14 @@ class CNState3:
     def cnt3(self) -> Tensor:
         return self.b.cnt1
 
-    def weights(self, innerprod: Tensor):
+    def weights(self, innerprod: Tensor, sharded: bool = False):
+        """``sharded``: the histograms were summed over edge shards — the closed form over the global counts is
+        used (the order-exact sums need every rank's entries in order; cn5 chains them through ocn_amd.dist.ring_colsum,
+        the two-stage cn6 does not)."""
         assert self.a._hist_live and self.b._hist_live, "histograms already consumed"
         self.a._hist_live = self.b._hist_live = False
-        return ops.cn_weights_cn6(self.a.hist, self.b.hist, innerprod)
+        exact = None if sharded else (self.adj._rowptr, self.adj._col, self.a.src, self.a.off, self.a.flags, self.b.flags)
+        return ops.cn_weights_cn6(self.a.hist, self.b.hist, innerprod, exact=exact)
 
     def gather(self, wa: Tensor, wb: Tensor, nip: Tensor, h: Tensor):
         return ops.cn_gather3(self.adj._rowptr, self.adj._col, self.a.src, self.a.dst, self.a.off, self.a.flags,

@@ -90,3 +90,45 @@ def test_single_process_helpers_are_identity():
     assert allreduce_hist(h) is h
     x = torch.randn(6, 1)
     assert gather_scores(x, 6) is x
+
+
+def _ring_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ocn_amd.dist import ring_colsum
+        n = 257
+        g = torch.Generator().manual_seed(11)
+        vals = (torch.rand(world, 5, n, generator=g) - 0.5) * torch.tensor([1e-3, 1.0, 1e4, 1.0, 1e-2]).view(1, 5, 1)
+
+        def run(init):                                       # this shard's entries, added one by one after the predecessor's sum
+            acc = init.clone()
+            for k in range(5):
+                acc = acc + vals[rank, k]
+            return acc
+
+        got = ring_colsum(run, n, torch.device("cpu"))
+        want = torch.zeros(n)
+        for r in range(world):
+            for k in range(5):
+                want = want + vals[r, k]
+        out.put((rank, bool(torch.equal(got, want))))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ring_colsum_continues_the_chain_through_the_ranks():
+    """ring_colsum: every rank ends with the SEQUENTIAL fp32 sum over all shards in rank order (not a tree sum)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ring_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
