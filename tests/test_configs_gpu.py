@@ -103,7 +103,19 @@ def test_baseline_config_end_to_end(hiplib, cfg):
         else:
             cn1, cn2 = adjoverlap(adj, adj, ed), adjoverlap(adj, adj2, ed)
         out2 = pred(h_ref.to(DEV), adj, cn1, cn2, ed, args)
-    assert close(out2, ref), (out2.cpu() - ref).abs().max()
+    if lnnn:
+        assert close(out2, ref), (out2.cpu() - ref).abs().max()
+    else:
+        # No LayerNorm in the heads (citation2 command): the raw walk-count pool (hundreds) runs through three plain
+        # Linear layers and cancels down to a score of order one, so two CORRECT fp32 evaluations that merely sum
+        # in different orders differ by more than 1e-5.  The bar there: as close to the fp64 evaluation of the same
+        # heads (same fp32 pooled vectors) as the reference's own fp32 arithmetic is.
+        pool = O.cn5_pool(h_ref, c1, c2, _sd(pred)["innerprod"])[:2] if pname == "cn5" else O.cn7_pool(h_ref, c1, c2, sum_fill)[:2]
+        sd64 = {k: v.double() for k, v in _sd(pred).items()}
+        ref64 = O._heads(sd64, h_ref.double(), pool[0].double(), pool[1].double(), e, lnnn, False, False)
+        noise = (ref.double() - ref64).abs().max().item()
+        err = (out2.cpu().double() - ref64).abs().max().item()
+        assert err <= 1e-5 + 1e-5 * ref.abs().max().item() + 2 * noise, (err, noise)
 
 
 def test_score_edges_equals_the_drivers_batch_loop(hiplib):
