@@ -110,8 +110,9 @@ def test_baseline_config_end_to_end(hiplib, cfg):
         # Linear layers and cancels down to a score of order one, so two CORRECT fp32 evaluations that merely sum
         # in different orders differ by more than 1e-5.  The bar there: as close to the fp64 evaluation of the same
         # heads (same fp32 pooled vectors) as the reference's own fp32 arithmetic is.
-        pool = O.cn5_pool(h_ref, c1, c2, _sd(pred)["innerprod"])[:2] if pname == "cn5" else O.cn7_pool(h_ref, c1, c2, sum_fill)[:2]
-        sd64 = {k: v.double() for k, v in _sd(pred).items()}
+        sdc = {k: v.cpu() for k, v in _sd(pred).items()}
+        pool = O.cn5_pool(h_ref, c1, c2, sdc["innerprod"])[:2] if pname == "cn5" else O.cn7_pool(h_ref, c1, c2, sum_fill)[:2]
+        sd64 = {k: v.double() for k, v in sdc.items()}
         ref64 = O._heads(sd64, h_ref.double(), pool[0].double(), pool[1].double(), e, lnnn, False, False)
         noise = (ref.double() - ref64).abs().max().item()
         err = (out2.cpu().double() - ref64).abs().max().item()
