@@ -35,8 +35,14 @@ extern "C" {
 
 int ocn_abi_version(void);
 
-/* Scratch bytes the scan entries need for `n` items. */
+/* Scratch bytes the scan entries need for `n` items.  The workspace must be ZERO when first handed to the library
+ * (the caller zeroes it once, when it allocates it); every entry leaves it zero again, so it can be reused from call
+ * to call — inputs beyond one tile are scanned by a single launch whose tiles chain through this state. */
 int64_t ocn_scan_workspace_bytes(int64_t n);
+
+/* Zero up to 8 device arrays (4-byte aligned, byte counts multiples of 4) with one launch: the per-batch reset of
+ * the histogram / counters / status words. */
+int ocn_zero_regions(void* const* ptrs, const int64_t* bytes, int32_t n, void* stream);
 
 /* off[e] = sum_{e'<e} deg_A(src[e']), off[B] = total: where each batch row starts in the
  * flag buffer.  Replaces the row bookkeeping of SparseTensor.__getitem__ (utils.py:256). */
@@ -53,7 +59,8 @@ int ocn_check_edges(const int64_t* src, const int64_t* dst, int64_t B, int64_t n
 /* A processing order for a candidate batch: order[] = the batch rows counting-sorted by the node id
  * in `node` (arbitrary order among equal ids).  Visiting rows with the same / nearby source node
  * together lets the rows they share be served from L2; it never changes a result.
- * workspace: ocn_order_workspace_bytes(n_nodes) bytes of device scratch. */
+ * workspace: ocn_order_workspace_bytes(n_nodes) bytes of device scratch, ZERO when first handed over and left zero
+ * (per-node counters that each batch row clears again, and the scan state). */
 int64_t ocn_order_workspace_bytes(int64_t n_nodes);
 int ocn_order_by_node(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* order, void* workspace,
                       void* stream);
@@ -141,7 +148,9 @@ int ocn_walk_rev_offsets(const int64_t* rowptrA, const int64_t* nds, const int64
  * cn5 (model.py:2261-2272, 2352-2413): w1 = 1/S1 (0 if S1 < 2); scale = max w1 over cn1
  * entries; nip = innerprod/scale (scale>0); t = nip*w1; S2 = column sums of cn2 - nip*ncn1 over
  * the union pattern (0 -> 1); inv2 = 1/S2.  `innerprod` is a device float[1] (the module buffer);
- * `scalars` is a device scratch of 4 int32, zero on entry; `valued` != 0 for walk-count cn2.
+ * `scalars` is the statistics word of ocn_cn5_column_stats — run that entry first whenever innerprod may be
+ * non-zero; for innerprod == 0 (a fresh model) nip is 0 whatever the scale, and zeroed scalars suffice;
+ * `valued` != 0 for walk-count cn2.
  * cn7 (model.py:3114-3126, 3186-3209): w1 = 1/S1, `sum_fill` where S1 < 2; cn2 raw ->
  * {w1, 0, 1, 0}. */
 int ocn_cn_weights_cn5(uint64_t* hist, int64_t N, const float* innerprod, int32_t* scalars,

@@ -23,6 +23,7 @@ ABI_VERSION = 2
 SIGNATURES = {
     "ocn_abi_version": (c_int32, []),
     "ocn_scan_workspace_bytes": (c_int64, [c_int64]),
+    "ocn_zero_regions": (c_int32, [_P, _P, c_int32, _P]),
     "ocn_check_edges": (c_int32, [_P, _P, c_int64, c_int64, c_int64, _P, _P]),
     "ocn_edge_offsets": (c_int32, [_P, _P, c_int64, _P, _P, _P]),
     "ocn_class_order": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),

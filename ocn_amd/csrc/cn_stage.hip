@@ -1243,8 +1243,6 @@ int ocn_cn_weights_cn5(uint64_t* hist, int64_t N, const float* innerprod, int32_
   if (N == 0) return 0;
   const int grid = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(cn5_column_stats, dim3(grid < 512 ? grid : 512), dim3(OCN_BLOCK), 0, st,
-                     (const u64*)hist, (i64)N, scalars);
   hipLaunchKernelGGL(cn5_column_weights, dim3(grid), dim3(OCN_BLOCK), 0, st, (u64*)hist, (i64)N,
                      innerprod, (const int32_t*)scalars, (int)valued, s2_exact);
   return launch_status();
@@ -1256,8 +1254,6 @@ int ocn_cn_weights_cn6(uint64_t* histA, uint64_t* histB, int64_t N, const float*
   if (N == 0) return 0;
   const int grid = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(cn5_column_stats, dim3(grid < 512 ? grid : 512), dim3(OCN_BLOCK), 0, st,
-                     (const u64*)histA, (i64)N, scalars);
   hipLaunchKernelGGL(cn6_column_weights, dim3(grid), dim3(OCN_BLOCK), 0, st, (u64*)histA, (u64*)histB, (i64)N,
                      innerprod, (const int32_t*)scalars, nip_out, s2_exact, s3_exact);
   return launch_status();

@@ -224,9 +224,9 @@ __global__ __launch_bounds__(OCN_BLOCK) void colsum_long_kernel(
 extern "C" {
 
 int64_t ocn_cn_colsum_workspace_bytes(int64_t N, int64_t flags_cap) {
-  // col_off int64[N+1] | counts/cursor int32[N] | long_list int32[N] | tickets int32[4] | entries uint32[cap] | scan ws
+  // col_off int64[N+1] | counts/cursor int32[N] | long_list int32[N] | tickets int32[4] | scan state | entries uint32[cap]
   const int64_t a = ((N + 1) * 8 + 15) / 16 * 16, b = (N * 4 + 15) / 16 * 16;
-  return a + 2 * b + 16 + (flags_cap * 4 + 15) / 16 * 16 + ocn_scan_workspace_bytes(N) + 64;
+  return a + 2 * b + 16 + (ocn_scan_workspace_bytes(N) + 15) / 16 * 16 + (flags_cap * 4 + 15) / 16 * 16 + 64;
 }
 
 int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, int64_t B,
@@ -245,13 +245,14 @@ int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64
   int32_t* counts = (int32_t*)(ws + a);
   int32_t* long_list = (int32_t*)(ws + a + b);
   int32_t* tickets = (int32_t*)(ws + a + 2 * b);                    // [0] number of long columns, [1] work ticket
-  uint32_t* entries = (uint32_t*)(ws + a + 2 * b + 16);
-  void* scan_ws = (void*)(ws + a + 2 * b + 16 + (flags_cap * 4 + 15) / 16 * 16);
+  void* scan_ws = (void*)(ws + a + 2 * b + 16);
+  const int64_t sw = (ocn_scan_workspace_bytes(N) + 15) / 16 * 16;
+  uint32_t* entries = (uint32_t*)(ws + a + 2 * b + 16 + sw);
   const int gridN = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
   const int gridB = grid_for((B + OCN_WPB - 1) / OCN_WPB, 1 << 16);
   int rc = ocn_cn5_column_stats(hist, N, scalars, stream);           // nip needs the batch's scale (idempotent)
   if (rc) return rc;
-  hipLaunchKernelGGL(colsum_zero_kernel, dim3(1), dim3(OCN_BLOCK), 0, st, tickets, (i64)4);
+  hipLaunchKernelGGL(colsum_zero_kernel, dim3(1), dim3(OCN_BLOCK), 0, st, tickets, (i64)(4 + sw / 4));   // + the scan state
   if (flagsB || s2_init) {        // cn6: the union is wider than histA's n_union; a shard: hist holds the GLOBAL counts
     hipLaunchKernelGGL(colsum_zero_kernel, dim3(gridN), dim3(OCN_BLOCK), 0, st, counts, (i64)N);
     if (B > 0)

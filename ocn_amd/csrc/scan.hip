@@ -85,66 +85,6 @@ struct I32In {
   __device__ __forceinline__ i64 operator()(i64 e) const { return (i64)in[e]; }
 };
 
-template <typename Op>
-__global__ __launch_bounds__(OCN_BLOCK) void scan_tile_sums(Op op, i64 n, i64* tile_sum) {
-  __shared__ i64 sh[OCN_WPB];
-  const i64 base = (i64)blockIdx.x * SCAN_TILE;
-  i64 s = 0;
-#pragma unroll
-  for (int t = 0; t < SCAN_IPT; ++t) {
-    i64 e = base + (i64)t * OCN_BLOCK + threadIdx.x;
-    if (e < n) s += op(e);
-  }
-  s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    i64 t = 0;
-    for (int i = 0; i < OCN_WPB; ++i) t += sh[i];
-    tile_sum[blockIdx.x] = t;
-  }
-}
-
-// one block: exclusive scan of tile_sum[0..nt) in place, tile_sum[nt] = total
-__global__ __launch_bounds__(OCN_BLOCK) void scan_spine(i64* tile_sum, i64 nt) {
-  __shared__ i64 sh[2 * OCN_WPB];
-  i64 carry = 0;
-  for (i64 c0 = 0; c0 < nt; c0 += OCN_BLOCK) {
-    i64 idx = c0 + threadIdx.x;
-    i64 v = idx < nt ? tile_sum[idx] : 0;
-    i64 tot;
-    i64 ex = block_excl_scan(v, sh, &tot);
-    if (idx < nt) tile_sum[idx] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) tile_sum[nt] = carry;
-}
-
-template <typename Op>
-__global__ __launch_bounds__(OCN_BLOCK) void scan_apply(Op op, i64 n, const i64* tile_sum, i64 nt,
-                                                        i64* out) {
-  __shared__ i64 sh[2 * OCN_WPB];
-  // thread-contiguous items so that the prefix order is the item order
-  const i64 base = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_IPT;
-  i64 v[SCAN_IPT];
-  i64 s = 0;
-#pragma unroll
-  for (int t = 0; t < SCAN_IPT; ++t) {
-    i64 e = base + t;
-    v[t] = e < n ? op(e) : 0;
-    s += v[t];
-  }
-  i64 tot;
-  i64 ex = block_excl_scan(s, sh, &tot) + tile_sum[blockIdx.x];
-#pragma unroll
-  for (int t = 0; t < SCAN_IPT; ++t) {
-    i64 e = base + t;
-    if (e < n) out[e] = ex;
-    ex += v[t];
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = tile_sum[nt];
-}
-
 // small inputs (a ppa / citation2 batch has 2048 rows): the whole scan in one workgroup, one launch
 #define SCAN_SINGLE_MAX (8 * SCAN_TILE)
 template <typename Op>
@@ -174,6 +114,70 @@ __global__ __launch_bounds__(OCN_BLOCK) void scan_single(Op op, i64 n, i64* out)
   if (threadIdx.x == 0) out[n] = carry;
 }
 
+// Large inputs: ONE launch, tiles chained through device memory.  A workgroup draws its tile from a ticket
+// (so every predecessor tile has started, whatever the dispatch order), publishes its tile total as one 8-byte
+// granule {ready bit | total} (relaxed agent-scope store: the granule carries its own tag, no fence), and wave 0
+// sums the granules of ALL earlier tiles, 64 per round, polling the ones not yet published.  The last workgroup
+// to finish clears the state, so the workspace is left as it was found: ZERO (ocn_scan_workspace_bytes; the
+// caller zeroes it once, when it allocates it).  state[0] = ticket, state[1] = finished tiles, state[2 + t] = tile t.
+#define SCAN_READY (1ull << 63)
+#define SCAN_SPIN_MAX (1 << 22)     /* bounded polling: a stale workspace gives wrong numbers, never a hang */
+template <typename Op>
+__global__ __launch_bounds__(OCN_BLOCK) void scan_chained(Op op, i64 n, i64* __restrict__ out, u64* __restrict__ state,
+                                                          i64 nt) {
+  __shared__ i64 sh[2 * OCN_WPB];
+  __shared__ i64 s_tile, s_prefix;
+  if (threadIdx.x == 0) s_tile = (i64)atomicAdd(&state[0], 1ull);
+  __syncthreads();
+  const i64 t = s_tile;
+  const i64 base = t * SCAN_TILE + (i64)threadIdx.x * SCAN_IPT;      // thread-contiguous items: prefix order = item order
+  i64 v[SCAN_IPT];
+  i64 s = 0;
+#pragma unroll
+  for (int q = 0; q < SCAN_IPT; ++q) {
+    const i64 e = base + q;
+    v[q] = e < n ? op(e) : 0;
+    s += v[q];
+  }
+  i64 tot;
+  i64 ex = block_excl_scan(s, sh, &tot);
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&state[2 + t], SCAN_READY | (u64)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x < OCN_WAVE) {
+    i64 prefix = 0;
+    for (i64 p0 = 0; p0 < t; p0 += OCN_WAVE) {
+      const i64 p = p0 + threadIdx.x;
+      u64 w = SCAN_READY;
+      if (p < t) {
+        int spins = 0;
+        do {
+          w = __hip_atomic_load(&state[2 + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!(w & SCAN_READY)) __builtin_amdgcn_s_sleep(1);
+        } while (!(w & SCAN_READY) && ++spins < SCAN_SPIN_MAX);
+      }
+      prefix += (i64)(w & ~SCAN_READY);
+    }
+    prefix = wave_sum(prefix);
+    if (threadIdx.x == 0) s_prefix = prefix;
+  }
+  __syncthreads();
+  ex += s_prefix;
+#pragma unroll
+  for (int q = 0; q < SCAN_IPT; ++q) {
+    const i64 e = base + q;
+    if (e < n) out[e] = ex;
+    ex += v[q];
+  }
+  if (t == nt - 1 && threadIdx.x == 0) out[n] = s_prefix + tot;
+  // the last workgroup to get here has no reader left behind it: leave the state zero for the next call
+  __syncthreads();
+  if (threadIdx.x == 0) s_tile = (i64)atomicAdd(&state[1], 1ull);
+  __syncthreads();
+  if (s_tile == nt - 1)
+    for (i64 q = threadIdx.x; q < nt + 2; q += OCN_BLOCK)
+      __hip_atomic_store(&state[q], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename Op>
 static int run_scan(Op op, i64 n, i64* out, void* ws, hipStream_t st) {
   if (n < 0 || !out || !ws) return OCN_EINVAL;
@@ -181,12 +185,8 @@ static int run_scan(Op op, i64 n, i64* out, void* ws, hipStream_t st) {
     hipLaunchKernelGGL(scan_single<Op>, dim3(1), dim3(OCN_BLOCK), 0, st, op, n, out);
     return launch_status();
   }
-  i64 nt = (n + SCAN_TILE - 1) / SCAN_TILE;
-  if (nt == 0) nt = 1;
-  i64* tile_sum = (i64*)ws;
-  hipLaunchKernelGGL(scan_tile_sums<Op>, dim3((unsigned)nt), dim3(OCN_BLOCK), 0, st, op, n, tile_sum);
-  hipLaunchKernelGGL(scan_spine, dim3(1), dim3(OCN_BLOCK), 0, st, tile_sum, nt);
-  hipLaunchKernelGGL(scan_apply<Op>, dim3((unsigned)nt), dim3(OCN_BLOCK), 0, st, op, n, tile_sum, nt, out);
+  const i64 nt = (n + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(scan_chained<Op>, dim3((unsigned)nt), dim3(OCN_BLOCK), 0, st, op, n, out, (u64*)ws, nt);
   return launch_status();
 }
 
@@ -195,23 +195,21 @@ static int run_scan(Op op, i64 n, i64* out, void* ws, hipStream_t st) {
 // order among rows with the same source), so that rows that gather the same neighbourhood are
 // visited back to back
 // ---------------------------------------------------------------------------------------------
-// (a kernel rather than hipMemsetAsync: the library then enqueues nothing but kernel nodes, so a captured
-// candidate batch replays as a pure kernel graph)
-__global__ __launch_bounds__(OCN_BLOCK) void zero_i32_kernel(int32_t* __restrict__ p, i64 n) {
-  for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (i64)gridDim.x * blockDim.x) p[q] = 0;
-}
-
 __global__ __launch_bounds__(OCN_BLOCK) void order_count(const i64* __restrict__ node, i64 B,
                                                          int32_t* __restrict__ counts) {
   for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < B; e += (i64)gridDim.x * blockDim.x)
     atomicAdd(counts + node[e], 1);
 }
 
+// (the counters were consumed by the scan: each row clears the one it raised, so the workspace is left zero)
 __global__ __launch_bounds__(OCN_BLOCK) void order_scatter(const i64* __restrict__ node, i64 B,
                                                            unsigned long long* __restrict__ cursor,
-                                                           i64* __restrict__ order) {
-  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < B; e += (i64)gridDim.x * blockDim.x)
-    order[atomicAdd(cursor + node[e], 1ull)] = e;
+                                                           i64* __restrict__ order, int32_t* __restrict__ counts) {
+  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < B; e += (i64)gridDim.x * blockDim.x) {
+    const i64 v = node[e];
+    order[atomicAdd(cursor + v, 1ull)] = e;
+    counts[v] = 0;
+  }
 }
 
 __global__ __launch_bounds__(OCN_BLOCK) void check_edges_kernel(const i64* __restrict__ src, const i64* __restrict__ dst,
@@ -224,9 +222,46 @@ __global__ __launch_bounds__(OCN_BLOCK) void check_edges_kernel(const i64* __res
   if (__ballot(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
 }
 
+// several small scratch arrays zeroed by ONE launch (a candidate batch resets its histogram, counters and status
+// words: as separate fills that was four launches of a few microseconds each)
+#define ZERO_MAX_REGIONS 8
+struct ZeroArgs { int n; uint32_t* p[ZERO_MAX_REGIONS]; i64 words[ZERO_MAX_REGIONS]; };
+__global__ __launch_bounds__(OCN_BLOCK) void zero_regions_kernel(const ZeroArgs a) {
+  i64 total = 0;
+  for (int r = 0; r < a.n; ++r) total += (a.words[r] + 3) >> 2;          // in 16-byte quads
+  for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (i64)gridDim.x * blockDim.x) {
+    i64 o = q;
+    int r = 0;
+    while (o >= ((a.words[r] + 3) >> 2)) { o -= (a.words[r] + 3) >> 2; ++r; }
+    uint32_t* base = a.p[r] + 4 * o;
+    const i64 left = a.words[r] - 4 * o;
+    if (left >= 4 && ((uintptr_t)base & 15) == 0) *reinterpret_cast<uint4*>(base) = make_uint4(0u, 0u, 0u, 0u);
+    else for (int k = 0; k < 4 && k < left; ++k) base[k] = 0u;
+  }
+}
+
 extern "C" {
 
 int64_t ocn_scan_workspace_bytes(int64_t n);
+
+int ocn_zero_regions(void* const* ptrs, const int64_t* bytes, int32_t n, void* stream) {
+  if (n < 0 || n > ZERO_MAX_REGIONS || (n > 0 && (!ptrs || !bytes))) return OCN_EINVAL;
+  ZeroArgs a;
+  a.n = 0;
+  i64 quads = 0;
+  for (int r = 0; r < n; ++r) {
+    if (bytes[r] < 0 || (bytes[r] & 3) || (bytes[r] > 0 && (!ptrs[r] || ((uintptr_t)ptrs[r] & 3)))) return OCN_EINVAL;
+    if (bytes[r] == 0) continue;
+    a.p[a.n] = (uint32_t*)ptrs[r];
+    a.words[a.n] = bytes[r] >> 2;
+    quads += (a.words[a.n] + 3) >> 2;
+    ++a.n;
+  }
+  if (a.n == 0) return 0;
+  hipLaunchKernelGGL(zero_regions_kernel, dim3(grid_for((quads + OCN_BLOCK - 1) / OCN_BLOCK, 2048)), dim3(OCN_BLOCK), 0,
+                     (hipStream_t)stream, a);
+  return launch_status();
+}
 
 int ocn_check_edges(const int64_t* src, const int64_t* dst, int64_t B, int64_t n_src, int64_t n_dst, int32_t* bad,
                     void* stream) {
@@ -254,9 +289,6 @@ int ocn_order_by_node(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* 
   void* scan_ws = (void*)(offs + n_nodes + 1);
 #ifdef OCN_X_ORDER_MEMSET   /* experiment of tools/graph_fault_ab.py only: the round-1 form, a memset node in a captured batch */
   if (hipMemsetAsync(counts, 0, (size_t)n_nodes * 4, st) != hipSuccess) return OCN_EINVAL;
-#else
-  hipLaunchKernelGGL(zero_i32_kernel, dim3(grid_for((n_nodes + OCN_BLOCK - 1) / OCN_BLOCK, 1024)), dim3(OCN_BLOCK), 0, st,
-                     counts, (i64)n_nodes);
 #endif
   const int grid = grid_for((B + OCN_BLOCK - 1) / OCN_BLOCK, 1024);
   hipLaunchKernelGGL(order_count, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)node, (i64)B, counts);
@@ -264,7 +296,7 @@ int ocn_order_by_node(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* 
   int rc = run_scan(op, (i64)n_nodes, offs, scan_ws, st);
   if (rc) return rc;
   hipLaunchKernelGGL(order_scatter, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)node, (i64)B,
-                     (unsigned long long*)offs, (i64*)order);
+                     (unsigned long long*)offs, (i64*)order, counts);
   return launch_status();
 }
 
@@ -273,7 +305,7 @@ int ocn_abi_version(void) { return OCN_ABI_VERSION; }
 
 int64_t ocn_scan_workspace_bytes(int64_t n) {
   i64 nt = (n + SCAN_TILE - 1) / SCAN_TILE;
-  return (nt + 2) * (int64_t)sizeof(i64);
+  return (nt + 4) * (int64_t)sizeof(i64);
 }
 
 int ocn_edge_offsets(const int64_t* rowptrA, const int64_t* src, int64_t B, int64_t* off,

@@ -68,24 +68,40 @@ def _req(t: Tensor, dtype, name: str, ndim: Optional[int] = None) -> Tensor:
 
 
 def _ws(n: int, device) -> Tensor:
-    return torch.empty(int(_lib.lib().ocn_scan_workspace_bytes(n)) // 8 + 1, dtype=torch.int64, device=device)
+    return torch.zeros(int(_lib.lib().ocn_scan_workspace_bytes(n)) // 8 + 1, dtype=torch.int64, device=device)
 
 
-def buf(ws, name: str, shape, dtype, device, zero: bool = False) -> Tensor:
+def buf(ws, name: str, shape, dtype, device, zero: bool = False, zero_init: bool = False) -> Tensor:
     """Scratch tensor.  ``ws`` = None: a fresh allocation (states the caller keeps: tests, materialize).
     ``ws`` = a dict owned by a predictor: the buffer is cached by (name, shape, dtype) and reused by the
     next batch — stream order makes that safe, and a dozen allocator round trips per batch disappear
-    from the host's critical path."""
+    from the host's critical path.  ``zero``: cleared on every call; ``zero_init``: cleared when it is
+    allocated only (workspaces the library hands back zero: ocn_hip.h, ocn_scan_workspace_bytes)."""
     shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
     if ws is None:
-        return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=device)
+        return (torch.zeros if (zero or zero_init) else torch.empty)(shape, dtype=dtype, device=device)
     key = (name, shape, dtype, str(device))
     t = ws.get(key)
     if t is None:
-        t = ws[key] = torch.empty(shape, dtype=dtype, device=device)
+        t = ws[key] = (torch.zeros if zero_init else torch.empty)(shape, dtype=dtype, device=device)
     if zero:
         t.zero_()
     return t
+
+
+def zero_regions(tensors) -> None:
+    """One launch that zeroes every tensor of the list (contiguous, 4-byte element multiples)."""
+    ts = [t for t in tensors if t is not None and t.numel()]
+    if not ts:
+        return
+    n = len(ts)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    nbytes = (ctypes.c_int64 * n)(*[t.numel() * t.element_size() for t in ts])
+    idx = ts[0].device.index
+    if idx != torch._C._cuda_getDevice():
+        with torch.cuda.device(idx):
+            return zero_regions(ts)
+    check(_lib.lib().ocn_zero_regions(ptrs, nbytes, n, stream_ptr()), "ocn_zero_regions")
 
 
 @_on_device
@@ -94,7 +110,7 @@ def edge_offsets(rowptr: Tensor, src: Tensor, wsd=None) -> Tensor:
     _req(src, torch.int64, "src", 1)
     B = src.numel()
     off = buf(wsd, "off", B + 1, torch.int64, src.device)
-    ws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, src.device)
+    ws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, src.device, zero_init=True)
     check(_lib.lib().ocn_edge_offsets(ptr(rowptr), ptr(src), B, ptr(off), ptr(ws), stream_ptr()),
           "ocn_edge_offsets")
     return off
@@ -163,7 +179,8 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     """Intersection pass.  ``walk=False``: flags of N(src) against the rows of dst in t1 (and t2).
     ``walk=True``: the pygho route on A itself (t1/t2 ignored): cn1 flags + walk counts; with ``nds``
     (``neighbor_degree_sum`` of A) every batch row is swept from its cheaper endpoint.
-    Returns (order|None, off, flags, wc|None, hist[N,2] int64 packed, cnt1, cnt2|None, status)."""
+    Returns (order|None, off, flags, wc|None, hist[N,2] int64 packed, cnt1, cnt2|None, status, scal) — ``scal``
+    is the zeroed int32[4] statistics scratch the weights stage of the same batch uses."""
     dev = src.device
     B = src.numel()
     _req(rowptrA, torch.int64, "rowptrA", 1); _req(colA, torch.int32, "colA", 1)
@@ -183,7 +200,7 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     if B >= sort_edges_min_batch:
         order = buf(wsd, "order", B, torch.int64, dev)
         n_src = rowptrA.numel() - 1
-        ows = buf(wsd, "order_ws", int(_lib.lib().ocn_order_workspace_bytes(n_src)) // 8 + 1, torch.int64, dev)
+        ows = buf(wsd, "order_ws", int(_lib.lib().ocn_order_workspace_bytes(n_src)) // 8 + 1, torch.int64, dev, zero_init=True)
         check(_lib.lib().ocn_order_by_node(ptr(src), B, n_src, ptr(order), ptr(ows), stream_ptr()),
               "ocn_order_by_node")
     off = edge_offsets(rowptrA, src, wsd)
@@ -191,9 +208,12 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     cap = bound if bound <= FLAGS_NOSYNC_LIMIT else int(off[-1].item())
     flags = buf(wsd, "flags", max(cap, 1), torch.uint8, dev)
     wc = buf(wsd, "wc", max(cap, 1), torch.int32, dev) if walk else None
-    hist = buf(wsd, "hist", (n_cols, 2), torch.int64, dev, zero=True)
-    cnt1 = buf(wsd, "cnt1", B, torch.int32, dev, zero=walk)
-    cnt2 = buf(wsd, "cnt2", B, torch.int32, dev, zero=walk) if (walk or t2 is not None) else None
+    hist = buf(wsd, "hist", (n_cols, 2), torch.int64, dev)
+    cnt1 = buf(wsd, "cnt1", B, torch.int32, dev)
+    cnt2 = buf(wsd, "cnt2", B, torch.int32, dev) if (walk or t2 is not None) else None
+    status = buf(wsd, "status", 4, torch.int32, dev)     # [0] overflow flag; [1], [2] walk-route work tickets
+    scal = buf(wsd, "scal", 4, torch.int32, dev)         # the column statistics word of the weights stage
+    zero_regions([hist, status, scal] + ([cnt1, cnt2] if walk else []))      # the batch's reset: one launch
     chunk_off = rev_off = None
     if walk:
         if nds is not None and walk_two_sided:
@@ -203,14 +223,13 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
         else:
             nds = None
         chunk_off = buf(wsd, "chunk_off", B + 1, torch.int64, dev)
-        cws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, dev)
+        cws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, dev, zero_init=True)
         check(_lib.lib().ocn_chunk_offsets(ptr(rowptrA), ptr(nds), ptr(src), ptr(order), B, ptr(chunk_off), ptr(cws),
                                            stream_ptr()), "ocn_chunk_offsets")
         if nds is not None:
             rev_off = buf(wsd, "rev_off", B + 1, torch.int64, dev)
             check(_lib.lib().ocn_walk_rev_offsets(ptr(rowptrA), ptr(nds), ptr(src), ptr(dst), ptr(order), B,
                                                   ptr(rev_off), ptr(cws), stream_ptr()), "ocn_walk_rev_offsets")
-    status = buf(wsd, "status", 4, torch.int32, dev, zero=True)     # [0] overflow flag; [1], [2] walk-route work tickets
     _mark("cn_prep")
     if walk:
         check(_lib.lib().ocn_cn_walk_flags(ptr(rowptrA), ptr(colA), ptr(nds), ptr(src), ptr(dst), ptr(order), B,
@@ -228,7 +247,7 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
                                       ptr(src), ptr(dst), ptr(order), B, n_cols, ptr(off), ptr(flags), cap, ptr(hist),
                                       ptr(cnt1), ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_flags")
     _mark("cn_flags")
-    return order, off, flags, wc, hist, cnt1, cnt2, status
+    return order, off, flags, wc, hist, cnt1, cnt2, status, scal
 
 
 @_on_device
@@ -301,6 +320,8 @@ def cn_weights_cn5(hist: Tensor, innerprod: Tensor, valued: bool = False, wsd=No
     ip = _req(innerprod.detach().reshape(1).to(torch.float32), torch.float32, "innerprod", 1)
     if scal is None:
         scal = buf(wsd, "scal", 4, torch.int32, hist.device, zero=True)
+    if _ip_nonzero(innerprod) and s2_exact is None:     # the batch's scale statistic: only a non-zero innerprod reads it
+        check(_lib.lib().ocn_cn5_column_stats(ptr(hist), hist.shape[0], ptr(scal), stream_ptr()), "ocn_cn5_column_stats")
     check(_lib.lib().ocn_cn_weights_cn5(ptr(hist), hist.shape[0], ptr(ip), ptr(scal), int(valued), ptr(s2_exact),
                                         stream_ptr()), "ocn_cn_weights_cn5")
     _mark("cn_weights")
@@ -348,7 +369,7 @@ def class_order(cnt1: Tensor, cnt2: Optional[Tensor], order: Optional[Tensor], w
     inv = buf(wsd, "cls_inv", B, torch.int64, dev)
     ranges = buf(wsd, "cls_ranges", (CLASS_RANGES, 2), torch.int64, dev)
     prefix = buf(wsd, "cls_prefix", B + 1, torch.int64, dev)
-    ws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, dev)
+    ws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, dev, zero_init=True)
     check(_lib.lib().ocn_class_order(ptr(cnt1), ptr(cnt2), ptr(order), B, ptr(order2), ptr(inv), ptr(ranges),
                                      ptr(prefix), ptr(ws), stream_ptr()), "ocn_class_order")
     _mark("cn_class")
@@ -356,7 +377,7 @@ def class_order(cnt1: Tensor, cnt2: Optional[Tensor], order: Optional[Tensor], w
 
 
 @_on_device
-def cn_weights_cn6(histA: Tensor, histB: Tensor, innerprod: Tensor, exact=None):
+def cn_weights_cn6(histA: Tensor, histB: Tensor, innerprod: Tensor, exact=None, scal: Optional[Tensor] = None):
     """In place: histA -> float32 [N,4] {inv1, t, inv2, 0}, histB -> {1/S3, 0, 0, 0}; returns them and the
     device scalar nip (ocn_hip.h: ocn_cn_weights_cn6).  ``exact`` = (rowptrA, colA, src, off, flagsA, flagsB):
     order-exact S2 / S3 for a non-zero ``innerprod``, as for cn5."""
@@ -364,12 +385,15 @@ def cn_weights_cn6(histA: Tensor, histB: Tensor, innerprod: Tensor, exact=None):
     if histA.shape != histB.shape:
         raise ValueError("histA / histB shape mismatch")
     ip = _req(innerprod.detach().reshape(1).to(torch.float32), torch.float32, "innerprod", 1)
-    scal = torch.zeros(4, dtype=torch.int32, device=histA.device)
+    if scal is None:
+        scal = torch.zeros(4, dtype=torch.int32, device=histA.device)
     nip = torch.empty(1, dtype=torch.float32, device=histA.device)
     s2 = s3 = None
     if exact is not None and colsum_wanted(innerprod):
         rowptrA, colA, src, off, flagsA, flagsB = exact
         s2, s3 = cn_colsum_exact(rowptrA, colA, src, off, flagsA, flagsB, None, histA, innerprod, scal)
+    elif _ip_nonzero(innerprod):
+        check(_lib.lib().ocn_cn5_column_stats(ptr(histA), histA.shape[0], ptr(scal), stream_ptr()), "ocn_cn5_column_stats")
     check(_lib.lib().ocn_cn_weights_cn6(ptr(histA), ptr(histB), histA.shape[0], ptr(ip), ptr(scal), ptr(nip),
                                         ptr(s2), ptr(s3), stream_ptr()), "ocn_cn_weights_cn6")
     _mark("cn_weights")

@@ -64,7 +64,7 @@ class CNState:
         self.B = self.src.numel()
         self.N = adj.size(1)
         ops.check_edges(self.src, self.dst, adj.size(0), adj.size(0) if walk else t1.size(0))
-        (self.order, self.off, self.flags, self.wc, self.hist, self.cnt1, self.cnt2, self.status) = ops.cn_flags(
+        (self.order, self.off, self.flags, self.wc, self.hist, self.cnt1, self.cnt2, self.status, self.scal) = ops.cn_flags(
             adj._rowptr, adj._col, None if walk else (t1._rowptr, t1._col),
             None if (walk or t2 is None) else (t2._rowptr, t2._col), self.src, self.dst, self.N,
             adj.max_rowcount(), walk=walk, t2_bitmap=None if (walk or t2 is None) else t2._bitmap, wsd=ws,
@@ -83,10 +83,9 @@ class CNState:
     def weights_cn5(self, innerprod: Tensor) -> Tensor:
         assert self._hist_live, "histogram already consumed"
         self._hist_live = False
-        s2 = scal = None
+        s2, scal = None, self.scal                   # zeroed with the batch's other scratch (ops.cn_flags)
         if ops.colsum_wanted(innerprod):
             # innerprod != 0 (a trained checkpoint): S2 summed entry by entry in the reference's order
-            scal = ops.buf(self.ws, "scal", 4, torch.int32, self.hist.device, zero=True)
             run = lambda init: ops.cn_colsum_exact(self.adj._rowptr, self.adj._col, self.src, self.off, self.flags, None,
                                                    self.wc, self.hist, innerprod, scal, self.ws, s2_init=init)[0]
             if getattr(self, "sharded", False):
@@ -205,7 +204,7 @@ class CNState3:
         assert self.a._hist_live and self.b._hist_live, "histograms already consumed"
         self.a._hist_live = self.b._hist_live = False
         exact = None if sharded else (self.adj._rowptr, self.adj._col, self.a.src, self.a.off, self.a.flags, self.b.flags)
-        return ops.cn_weights_cn6(self.a.hist, self.b.hist, innerprod, exact=exact)
+        return ops.cn_weights_cn6(self.a.hist, self.b.hist, innerprod, exact=exact, scal=self.a.scal)
 
     def gather(self, wa: Tensor, wb: Tensor, nip: Tensor, h: Tensor):
         return ops.cn_gather3(self.adj._rowptr, self.adj._col, self.a.src, self.a.dst, self.a.off, self.a.flags,

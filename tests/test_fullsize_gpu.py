@@ -54,7 +54,7 @@ def test_graph_capture_of_a_65536_edge_step_replays_bitwise(collab):
 # ---- the walk route at full size: ppa- and citation2-shaped graphs, B = 2048 -----------------------------
 def _walk_raw(adj, e, nds):
     from ocn_amd import ops
-    order, off, flags, wc, hist, c1, c2, status = ops.cn_flags(
+    order, off, flags, wc, hist, c1, c2, status, _ = ops.cn_flags(
         adj._rowptr, adj._col, None, None, e[0].contiguous(), e[1].contiguous(), adj.size(1), adj.max_rowcount(),
         walk=True, nds=nds)
     n = int(off[-1])

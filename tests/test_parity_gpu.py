@@ -482,7 +482,7 @@ def test_walk_route_counts_values_and_pools(case):
 
 def _walk_raw(adj, e, nds):
     from ocn_amd import ops
-    order, off, flags, wc, hist, c1, c2, status = ops.cn_flags(
+    order, off, flags, wc, hist, c1, c2, status, _ = ops.cn_flags(
         adj._rowptr, adj._col, None, None, e[0].contiguous(), e[1].contiguous(), adj.size(1), adj.max_rowcount(),
         walk=True, nds=nds)
     n = int(off[-1])
