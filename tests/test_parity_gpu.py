@@ -585,11 +585,29 @@ def test_processing_order_is_a_permutation_grouped_by_source(hiplib):
     n, B = 100000, 50000
     src = torch.randint(0, n, (B,), device=DEV)
     order = torch.empty(B, dtype=torch.int64, device=DEV)
-    ws = torch.empty(int(hiplib.ocn_order_workspace_bytes(n)) // 8 + 1, dtype=torch.int64, device=DEV)
-    ops.check(hiplib.ocn_order_by_node(ops.ptr(src), B, n, ops.ptr(order), ops.ptr(ws), ops.stream_ptr()), "order")
-    assert torch.equal(torch.sort(order).values, torch.arange(B, device=DEV))
-    s = src[order]
-    assert bool((s[1:] >= s[:-1]).all())
+    # the workspace is handed over zeroed once and comes back zeroed (ocn_hip.h): two calls on the same buffer
+    ws = torch.zeros(int(hiplib.ocn_order_workspace_bytes(n)) // 8 + 1, dtype=torch.int64, device=DEV)
+    for _ in range(2):
+        ops.check(hiplib.ocn_order_by_node(ops.ptr(src), B, n, ops.ptr(order), ops.ptr(ws), ops.stream_ptr()), "order")
+        assert torch.equal(torch.sort(order).values, torch.arange(B, device=DEV))
+        s = src[order]
+        assert bool((s[1:] >= s[:-1]).all())
+        counters = ws[: (n * 4 + 15) // 16 * 2]                    # the per-node counters (int32[n], 16-byte padded)
+        assert not bool(counters.any()) and not bool(ws[-(int(hiplib.ocn_scan_workspace_bytes(n)) // 8):].any())
+        src = torch.randint(0, n, (B,), device=DEV)
+
+
+def test_chained_scan_matches_cumsum(hiplib):
+    """Inputs beyond one tile are scanned by one launch whose tiles chain through the workspace; it is left zero."""
+    from ocn_amd import ops
+    for n in (1, 2047, 16385, 100003, 3000017):
+        cnt = torch.randint(0, 1000, (n,), dtype=torch.int32, device=DEV)
+        ws = torch.zeros(int(hiplib.ocn_scan_workspace_bytes(n)) // 8 + 1, dtype=torch.int64, device=DEV)
+        out = torch.empty(n + 1, dtype=torch.int64, device=DEV)
+        for _ in range(2):
+            ops.check(hiplib.ocn_scan_i32(ops.ptr(cnt), n, ops.ptr(out), ops.ptr(ws), ops.stream_ptr()), "scan")
+            want = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), torch.cumsum(cnt.long(), 0)])
+            assert torch.equal(out, want) and not bool(ws.any())
 
 
 @pytest.mark.parametrize("H", [64, 256])
