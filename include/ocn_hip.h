@@ -319,6 +319,41 @@ int ocn_linear_bf16x6(const float* X, int64_t M, int32_t K, const void* Wp, int3
  * its weights).  `groups` is a HOST array. */
 int ocn_linear_grouped(const OcnLinearGroup* groups, int32_t n_groups, int32_t K, int32_t N, void* stream);
 
+/* The MLP heads of cn5 / cn7 (model.py:2203-2235, 2429-2437 == 3216-3223) as one launch per candidate batch:
+ *   a = ReLU(LN(W3a ReLU(W0a xcn1 + b0a) + b3a)),  b likewise from xcn2,  c = ReLU(LN(W0x (x_i*x_j) + b0x)),
+ *   y = Linear(H,1)(ReLU(LN(Ma a + Mb b + Mc c + bf)))
+ * where the host has folded the reference's products without a non-linearity between them — the third layers
+ * of xcn1lin / xcn2lin, the second layer of xijlin, the mix alpha0*xcn1 + alpha1*xcn2 + beta*xij (model.py:2436)
+ * and lin[0] — into Ma, Mb, Mc, bf.  Every activation stays in registers; only x[3] is read and y written.
+ * p_first: natural panels (ocn_linear_split_weight) of xcn1lin.0, xcn2lin.0, xijlin.0; p_mid: CHAINED panels
+ * (ocn_linear_split_weight_chained) of xcn1lin.3, xcn2lin.3; p_out: chained panels of Ma, Mb, Mc.
+ * vec: ocn_heads_nvec() vectors of H floats — b0a b3a g3a e3a  b0b b3b g3b e3b  b0x gx ex  bf gl el  dotw  constA constB
+ * — followed by the dot bias; constA / constB = Ma a, Mb b of an all-zero pooled row, obtained from this entry in
+ * dump mode (dump != NULL: one workgroup, row 0, writes dump[0][H], dump[1][H], no scores).  ranges (or NULL) =
+ * ocn_class_order's table: the candidates then come class-major and a workgroup without any cn1 (cn2) row adds the
+ * constant instead of running the branch; b_on_union: cn5 (xcn2 lives on cn1 u cn2) vs cn7 (cn2 only).
+ * H in {32, 64, 128, 256}; in_channels == H. */
+typedef struct OcnHeadsArgs {
+  const float* x[3];
+  int64_t ldx, B;
+  int32_t H;
+  const void* p_first[3];
+  const void* p_mid[2];
+  const void* p_out[3];
+  const float* vec;
+  const int64_t* ranges;
+  const int64_t* y_row_map;
+  float* y;
+  float* dump;
+  float* scratch;            /* ocn_heads_scratch_bytes(H) bytes: where a wave parks a finished branch's accumulators */
+  float eps;
+  int32_t ln, b_on_union;
+} OcnHeadsArgs;
+int32_t ocn_heads_nvec(void);
+int64_t ocn_heads_scratch_bytes(int32_t H);
+int ocn_linear_split_weight_chained(const float* W, int32_t N, int32_t K, void* Wp, void* stream);
+int ocn_heads_fused(const OcnHeadsArgs* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -61,6 +61,10 @@ SIGNATURES = {
     "ocn_linear_bf16x6": (c_int32, [_P, c_int64, c_int32, _P, c_int32, _P, _P, _P, c_float, c_int32, _P, _P,
                                     _P, _P]),
     "ocn_linear_grouped": (c_int32, [_P, c_int32, c_int32, c_int32, _P]),
+    "ocn_heads_nvec": (c_int32, []),
+    "ocn_heads_scratch_bytes": (c_int64, [c_int32]),
+    "ocn_linear_split_weight_chained": (c_int32, [_P, c_int32, c_int32, _P, _P]),
+    "ocn_heads_fused": (c_int32, [_P, _P]),
 }
 
 
@@ -75,6 +79,14 @@ class OcnLinearGroup(ctypes.Structure):
                 ("scale", c_void_p), ("addend", c_void_p), ("ldAdd", c_int64), ("dotw", c_void_p),
                 ("dotb", c_void_p), ("Y", c_void_p), ("ldY", c_int64), ("row_range", c_void_p),
                 ("y_row_map", c_void_p), ("add_bcast", c_int32)]
+
+
+class OcnHeadsArgs(ctypes.Structure):
+    """Mirror of ``OcnHeadsArgs`` in include/ocn_hip.h."""
+    _fields_ = [("x", c_void_p * 3), ("ldx", c_int64), ("B", c_int64), ("H", c_int32),
+                ("p_first", c_void_p * 3), ("p_mid", c_void_p * 2), ("p_out", c_void_p * 3),
+                ("vec", c_void_p), ("ranges", c_void_p), ("y_row_map", c_void_p), ("y", c_void_p),
+                ("dump", c_void_p), ("scratch", c_void_p), ("eps", c_float), ("ln", c_int32), ("b_on_union", c_int32)]
 
 
 def sources():

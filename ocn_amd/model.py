@@ -466,7 +466,8 @@ class _CNPredictorBase(nn.Module):
             return _PoolFn.apply(x, st, w)
         st.cls = None
         if (ops.skip_zero_rows and not self.training and not torch.is_grad_enabled() and st.B >= ops.skip_zero_min_batch
-                and st.cnt2 is not None and self._heads_plan(x.shape[1]) is not None and self._skip_worthwhile()):
+                and st.cnt2 is not None and (self._fused_plan(x.shape[1]) is not None or self._heads_plan(x.shape[1]) is not None)
+                and self._skip_worthwhile()):
             # class-major rows: candidates without cn1 / cn2 entries end up in contiguous ranges the heads skip
             # (the pooling keeps its own source-sorted, XCD-balanced processing order and only WRITES to the
             # class-major rows: processed class-major, the XCDs holding the heavy classes ran 50 % longer)
@@ -543,8 +544,8 @@ class _CNPredictorBase(nn.Module):
         return self.innerprod
 
     def _drop_caches(self) -> None:
-        self._coef_key = self._mixw_key = self._zc_key = self._plan_key = None
-        self._zc_params = None
+        self._coef_key = self._mixw_key = self._zc_key = self._plan_key = self._fplan_key = self._fpack_key = None
+        self._zc_params = self._fp_params = None
         for p in self.parameters():
             ops._panels.pop(id(p), None)
 
@@ -681,7 +682,93 @@ class _CNPredictorBase(nn.Module):
         ops.linear_grouped([dict(x=cat, weight=w3, bias=b3, relu=False, y=z, addend=y0)], 2 * H, H)
         return z
 
+    # ---- the whole head as one launch (ocn_heads_fused) -------------------------------------------------------------
+    def _fused_plan(self, H: int):
+        """The parsed head when it has the layout ocn_heads_fused evaluates (the drivers': 3-layer pooled heads, 1- or
+        2-layer xijlin, single-layer lin with the Linear(H, 1) tail, in_channels == hidden), else None."""
+        key = (H, ops.fused_heads)
+        if getattr(self, "_fplan_key", None) != key:
+            plan = None
+            if ops.fused_heads and H in ops.HEADS_WIDTHS:
+                sa, sb, sx = _stages(self.xcn1lin, H), _stages(self.xcn2lin, H), _stages(self.xijlin, H)
+                mods = [m for m in self.lin if not isinstance(m, (nn.Dropout, nn.Identity))]
+                sl = _stages(nn.Sequential(*mods[:-1]), H) if len(mods) >= 2 else None
+                tail = mods[-1] if mods else None
+
+                def pooled_ok(st):
+                    return (st is not None and len(st) == 3 and st[0][1] is None and st[0][2] and st[1][2]
+                            and st[2][1] is None and not st[2][2])
+                if (pooled_ok(sa) and pooled_ok(sb) and sx is not None and len(sx) in (1, 2) and sx[0][2]
+                        and (len(sx) == 1 or (sx[1][1] is None and not sx[1][2]))
+                        and sl is not None and len(sl) == 1 and sl[0][2]
+                        and isinstance(tail, nn.Linear) and tail.out_features == 1 and tail.in_features == H):
+                    lns = [sa[1][1], sb[1][1], sx[0][1], sl[0][1]]
+                    if all(l is None for l in lns) or (all(l is not None for l in lns) and len({l.eps for l in lns}) == 1):
+                        plan = (sa, sb, sx, sl[0], tail)
+            self._fplan, self._fplan_key = plan, key
+        return self._fplan
+
+    def _fused_pack(self, H: int, dev):
+        """Panels, folded output matrices, epilogue vectors and skipped-branch constants of ocn_heads_fused, cached on
+        the parameter versions.  Folding (fp64, rounded once): the products of the reference without a non-linearity
+        between them — third layers of xcn1lin / xcn2lin, second layer of xijlin, the mix of model.py:2436, lin[0]."""
+        sa, sb, sx, sl, tail = self._fused_plan(H)
+        plist = getattr(self, "_fp_params", None)
+        if plist is None:
+            plist = self._fp_params = [p for seq in (self.xcn1lin, self.xcn2lin, self.xijlin, self.lin) for p in seq.parameters()]
+        self._mix_coef()
+        key = (tuple(p._version for p in plist), tuple(p.data_ptr() for p in plist), self._coef_key, str(dev))
+        if getattr(self, "_fpack_key", None) == key:
+            return self._fpack
+        with torch.no_grad():
+            c = self._mix_coef().double()                       # [s(a0), s(a0) s(a1), beta]
+            W0l, b0l = sl[0].weight.double(), sl[0].bias.double()
+            Ma = c[0] * (W0l @ sa[2][0].weight.double())
+            Mb = c[1] * (W0l @ sb[2][0].weight.double())
+            bsum = c[0] * sa[2][0].bias.double() + c[1] * sb[2][0].bias.double()
+            if len(sx) == 2:
+                Mc = c[2] * (W0l @ sx[1][0].weight.double())
+                bsum = bsum + c[2] * sx[1][0].bias.double()
+            else:
+                Mc = c[2] * W0l
+            bf = W0l @ bsum + b0l
+            ln = sa[1][1] is not None
+            zeros, ones = torch.zeros(H, device=dev), torch.ones(H, device=dev)
+
+            def gb(l):
+                return (l.weight.float(), l.bias.float()) if l is not None else (ones, zeros)
+            vecs = [sa[0][0].bias, sa[1][0].bias, *gb(sa[1][1]), sb[0][0].bias, sb[1][0].bias, *gb(sb[1][1]),
+                    sx[0][0].bias, *gb(sx[0][1]), bf.float(), *gb(sl[1]), tail.weight.reshape(-1), zeros, zeros]
+            assert len(vecs) == int(ops._lib.lib().ocn_heads_nvec())
+            vec = torch.cat([v.detach().float().reshape(-1) for v in vecs] + [tail.bias.detach().float().reshape(1)]).contiguous()
+            pack = dict(first=[ops.linear_panel(sa[0][0].weight), ops.linear_panel(sb[0][0].weight), ops.linear_panel(sx[0][0].weight)],
+                        mid=[ops.linear_panel_chained(sa[1][0].weight), ops.linear_panel_chained(sb[1][0].weight)],
+                        out=[ops.linear_panel_chained(m.float().contiguous()) for m in (Ma, Mb, Mc)],
+                        vec=vec, ln=ln, eps=(sa[1][1].eps if ln else 1e-5), flops_per_row=2.0 * H * H * 8)
+            # the constants a skipped branch contributes: the branch's share of the output on an all-zero pooled row,
+            # computed by the kernel itself (dump mode) so that skipping changes no bit
+            z = torch.zeros(1, H, device=dev)
+            dump = torch.empty(2, H, device=dev)
+            scratch = ops.buf(self._ws, "heads_scratch", int(ops._lib.lib().ocn_heads_scratch_bytes(H)) // 4, torch.float32, dev)
+            ops.heads_fused(z, z, z, pack, None, None, self._xcn2_on_union, scratch, dump=dump)
+            nv = len(vecs)
+            vec[(nv - 2) * H:(nv - 1) * H] = dump[0]
+            vec[(nv - 1) * H:nv * H] = dump[1]
+        self._fpack, self._fpack_key = pack, key
+        return pack
+
+    def _heads_fused(self, xcn1, xcn2, xij, cls):
+        B, H = xij.shape
+        pack = self._fused_pack(H, xij.device)
+        scratch = ops.buf(self._ws, "heads_scratch", int(ops._lib.lib().ocn_heads_scratch_bytes(H)) // 4, torch.float32, xij.device)
+        ranges, rowmap = (None, None) if cls is None else (cls[2], cls[0])
+        return ops.heads_fused(xcn1, xcn2, xij, pack, ranges, rowmap, self._xcn2_on_union, scratch)
+
     def _heads(self, x, xcn1, xcn2, xij, cls=None):
+        if (not self.training and not torch.is_grad_enabled() and xij.is_cuda and xij.dim() == 2 and xij.shape[0] > 0
+                and xij.is_contiguous() and xcn1.is_contiguous() and xcn2.is_contiguous()
+                and xcn1.shape == xij.shape and self._fused_plan(xij.shape[1]) is not None):
+            return self._heads_fused(xcn1, xcn2, xij, cls)
         if cls is not None:
             return self._heads_skipping(xcn1, xcn2, xij, cls)
         if self.training or torch.is_grad_enabled() or not xij.is_cuda or xij.shape[-1] % 4:

@@ -568,6 +568,57 @@ def linear_panel(weight: Tensor) -> Tensor:
     return panel
 
 
+@_on_device
+def linear_panel_chained(weight: Tensor) -> Tensor:
+    """The CHAINED panel of a weight [N, K] (ocn_hip.h: ocn_linear_split_weight_chained): the k order in which the
+    previous layer's accumulator registers arrive in ocn_heads_fused.  Not cached here (the heads pack caches it)."""
+    w = _req(weight.detach(), torch.float32, "weight", 2)
+    N, K = w.shape
+    panel = torch.empty(int(_lib.lib().ocn_linear_panel_bytes(N, K)), dtype=torch.uint8, device=w.device)
+    check(_lib.lib().ocn_linear_split_weight_chained(ptr(w), N, K, ptr(panel), stream_ptr()), "ocn_linear_split_weight_chained")
+    return panel
+
+
+HEADS_WIDTHS = (32, 64, 128, 256)
+fused_heads = True               # cn5 / cn7 eval: the whole MLP head as one launch (ocn_heads_fused)
+
+
+@_on_device
+def heads_fused(x1: Tensor, x2: Tensor, xij: Tensor, pack: dict, ranges: Optional[Tensor], y_row_map: Optional[Tensor],
+                b_on_union: bool, scratch: Tensor, dump: Optional[Tensor] = None) -> Optional[Tensor]:
+    """ocn_hip.h: ocn_heads_fused.  ``pack``: panels / vectors prepared by ``model._CNPredictorBase._fused_pack``.
+    Returns the [B, 1] scores (or None in dump mode, where ``dump`` [2, H] receives the branch constants)."""
+    for t, nm in ((x1, "xcn1"), (x2, "xcn2"), (xij, "xij")):
+        _req(t, torch.float32, nm, 2)
+    B, H = xij.shape
+    if x1.shape != (B, H) or x2.shape != (B, H) or H not in HEADS_WIDTHS:
+        raise ValueError("heads_fused: shape mismatch")
+    a = _lib.OcnHeadsArgs()
+    a.x[0], a.x[1], a.x[2] = x1.data_ptr(), x2.data_ptr(), xij.data_ptr()
+    a.ldx, a.B, a.H = H, B, H
+    for i in range(3):
+        a.p_first[i] = pack["first"][i].data_ptr()
+        a.p_out[i] = pack["out"][i].data_ptr()
+    a.p_mid[0], a.p_mid[1] = pack["mid"][0].data_ptr(), pack["mid"][1].data_ptr()
+    a.vec = pack["vec"].data_ptr()
+    a.ranges = 0 if ranges is None else _req(ranges, torch.int64, "ranges").data_ptr()
+    a.y_row_map = 0 if y_row_map is None else _req(y_row_map, torch.int64, "y_row_map", 1).data_ptr()
+    y = None
+    if dump is None:
+        y = torch.empty((B, 1), dtype=torch.float32, device=xij.device)
+        a.y = y.data_ptr()
+    else:
+        a.dump = _req(dump, torch.float32, "dump", 2).data_ptr()
+    if scratch.numel() * scratch.element_size() < int(_lib.lib().ocn_heads_scratch_bytes(H)):
+        raise ValueError("heads_fused: scratch too small")
+    a.scratch = scratch.data_ptr()
+    a.eps, a.ln, a.b_on_union = float(pack["eps"]), int(pack["ln"]), int(bool(b_on_union))
+    _mark("mlp_glue")
+    check(_lib.lib().ocn_heads_fused(ctypes.byref(a), stream_ptr()), "ocn_heads_fused")
+    _mark("linear", pack["flops_per_row"] * B)
+    return y
+
+
 def linear_ok(x: Tensor, weight: Tensor) -> bool:
     return (fast_linear and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous()
             and weight.shape[0] in LINEAR_WIDTHS and weight.shape[1] % 16 == 0 and weight.shape[1] == x.shape[1])
