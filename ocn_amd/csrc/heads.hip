@@ -27,7 +27,6 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float v4f;
 
 #define HD_ROWS 128
 #define HD_KC 2                       /* k-steps per staged panel chunk */
@@ -74,7 +73,8 @@ struct Heads {
   static constexpr int CHUNK = HD_KC * PANEL;            // fragments per staged chunk
   static constexpr int NCH = (H / 16) / HD_KC;           // chunks per panel (== NT)
   static constexpr int VEC_FLOATS = 16 + (HD_NVEC * H + 4 + 3) / 4 * 4;   // 8 panel pointers, then the vectors
-  static constexpr size_t LDS_BYTES = (size_t)VEC_FLOATS * 4 + 2 * (size_t)CHUNK * 16;
+  static constexpr int XBUF = 4 * HD_KC * 2 * 64;        // float4 per landing buffer: 4 waves x k-steps x two 16-byte pieces x 64 lanes
+  static constexpr size_t LDS_BYTES = (size_t)VEC_FLOATS * 4 + 2 * (size_t)CHUNK * 16 + 2 * (size_t)XBUF * 16;
 
   // six cross terms of one k-step of one output tile (smallest first)
   static __device__ __forceinline__ void mma6(f32x16& acc, const bf16x8 (&wf)[3], const bf16x8 (&xf)[3]) {
@@ -171,11 +171,11 @@ struct Heads {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-// The candidates' input rows go straight to registers with inline-asm loads: beside LDS-DMA the compiler's own
+// Every load of the main loops is an LDS-DMA (weights AND the candidates' input rows): beside LDS-DMA the compiler's
 // wait-count bookkeeping drains the whole queue (vmcnt(0)) at the first use of an ordinary load's result
-// (cdna_hip_programming.md §5, trap 4b); these loads are waited for by hand at the chunk boundary instead.
-#define HD_GLOAD(dst, ptr, off) \
-  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "i"(off) : "memory")
+// (cdna_hip_programming.md §5, trap 4b), and asynchronous inline-asm loads into registers do not survive a loop
+// back edge (a compiler-inserted copy reads the register before the data lands).  A lane's 32 bytes of a k-step
+// land in its own slots of a per-wave LDS buffer and are read back by the same lane.
 
 template <int NT>
 __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsArgs a) {
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
   const bf16x8** s_list = reinterpret_cast<const bf16x8**>(smem);
   float* s_vec = reinterpret_cast<float*>(smem) + 16;
   bf16x8* s_w = reinterpret_cast<bf16x8*>(smem + (size_t)HD::VEC_FLOATS * 4);
+  float4* s_x = reinterpret_cast<float4*>(smem + (size_t)HD::VEC_FLOATS * 4 + 2 * (size_t)CHUNK * 16);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   for (int q = threadIdx.x; q < HD_NVEC * H + 1; q += OCN_BLOCK) s_vec[q] = a.vec[q];
@@ -231,32 +232,34 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
     issue(0);
 
     // ---- first layer of a branch from global memory: acc = W0 . X^T ------------------------------------------
+    // rows of chunk c (k-steps 2c, 2c+1) -> this wave's slots of landing buffer `buf`
+    auto issue_x = [&](const float* xrow, int c, int buf) {
+      float4* dst = s_x + (size_t)buf * HD::XBUF + (size_t)w * (HD_KC * 2 * 64);
+#pragma unroll
+      for (int ks = 0; ks < HD_KC; ++ks)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xrow + (c * HD_KC + ks) * 16 + 4 * pc),
+                                           (lds_ptr_t)(dst + (ks * 2 + pc) * 64), 16, 0, 0);
+    };
     auto first_layer = [&](f32x16 (&acc)[NT], const float* xb, bool rowmask) {
       const float* xrow = xb + arow * a.ldx + 8 * hh;
       HD::zero(acc);
-      v4f xn[HD_KC][2];
-#pragma unroll
-      for (int ks = 0; ks < HD_KC; ++ks) { HD_GLOAD(xn[ks][0], xrow, ks * 64); HD_GLOAD(xn[ks][1], xrow, ks * 64 + 16); }
+      issue_x(xrow, 0, gi & 1);
 #pragma unroll 1
       for (int c = 0; c < NCH; ++c) {
-        // chunk boundary — everything this wave issued has landed (vmcnt), everybody's has (barrier), nobody still
-        // reads the buffer chunk gi + 1 is about to overwrite — with the in-flight row registers tied to the wait
-        static_assert(HD_KC == 2, "the wait below names the registers of two k-steps");
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(xn[0][0]), "+v"(xn[0][1]), "+v"(xn[1][0]), "+v"(xn[1][1]) :: "memory");
+        // chunk boundary: everything this wave issued has landed (vmcnt), everybody's has (barrier), and nobody still
+        // reads the buffers chunk gi + 1 is about to overwrite
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        v4f xc[HD_KC][2];
-#pragma unroll
-        for (int ks = 0; ks < HD_KC; ++ks) { xc[ks][0] = xn[ks][0]; xc[ks][1] = xn[ks][1]; }
         issue(gi + 1);
-        if (c + 1 < NCH) {
-          const float* nx = xrow + (c + 1) * HD_KC * 16;
-#pragma unroll
-          for (int ks = 0; ks < HD_KC; ++ks) { HD_GLOAD(xn[ks][0], nx, ks * 64); HD_GLOAD(xn[ks][1], nx, ks * 64 + 16); }
-        }
+        if (c + 1 < NCH) issue_x(xrow, c + 1, (gi + 1) & 1);
         const bf16x8* wl = s_w + (size_t)(gi & 1) * CHUNK;
+        const float4* xl = s_x + (size_t)(gi & 1) * HD::XBUF + (size_t)w * (HD_KC * 2 * 64) + lane;
 #pragma unroll
         for (int ks = 0; ks < HD_KC; ++ks) {
-          float xs[8] = {xc[ks][0].x, xc[ks][0].y, xc[ks][0].z, xc[ks][0].w, xc[ks][1].x, xc[ks][1].y, xc[ks][1].z, xc[ks][1].w};
+          const float4 x0 = xl[(ks * 2) * 64], x1 = xl[(ks * 2 + 1) * 64];
+          float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
           for (int j = 0; j < 8; ++j) xs[j] = rowmask ? xs[j] : 0.f;         // rows the pooling never wrote count as zero rows
           bf16x8 xf[3];
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
     for (int br = 0; br < 2; ++br) {
       if (!(br == 0 ? wgA : wgB)) continue;
       const float* vb = s_vec + (br == 0 ? V_B0A : V_B0B) * H;                // b0, b3, gamma3, beta3 of this branch
-      first_layer(l1, a.x[br], br == 0 ? has1 : hasB);
+      first_layer(l1, br == 0 ? a.x[0] : a.x[1], br == 0 ? has1 : hasB);
       HD::add_vec(l1, vb, hh);
       HD::relu(l1);
       chained_layer(l2, l1);
