@@ -86,8 +86,12 @@ struct Heads {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[0], acc, 0, 0, 0);
   }
 
-  // one k-step: all NT output tiles, weight fragments from the staged chunk (A operand), xf = B operand
-  static __device__ __forceinline__ void kstep(f32x16 (&acc)[NT], const bf16x8* wl, const bf16x8 (&xf)[3], int lane) {
+  // one k-step: all NT output tiles, weight fragments from the staged chunk (A operand), xf = B operand.
+  // `between(t)` runs right after tile t's six MFMAs have been ISSUED — they then execute for ~190 cycles on their
+  // own: that is where the wave issues its LDS-DMA pieces and splits the next k-step's operand instead of idling
+  // the matrix pipe with them at the chunk boundary (one wave per SIMD: nobody else would fill it).
+  template <typename F>
+  static __device__ __forceinline__ void kstep(f32x16 (&acc)[NT], const bf16x8* wl, const bf16x8 (&xf)[3], int lane, F&& between) {
     bf16x8 wq[2][3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) wq[0][u] = wl[u * 64 + lane];
@@ -99,8 +103,21 @@ struct Heads {
       }
       __builtin_amdgcn_sched_barrier(0);     // keep the prefetch one tile deep: hoisted further, the fragments of a whole
       mma6(acc[t], wq[t & 1], xf);           // k-step would be live at once
+      between(t);
     }
     __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // split elements [j0, j1) of an operand fragment
+  static __device__ __forceinline__ void split_part(const float (&xs)[8], bf16x8 (&xf)[3], int j0, int j1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j >= j0 && j < j1) {
+        const __bf16 p = (__bf16)xs[j];
+        const float r1 = xs[j] - hd_bf(p);
+        const __bf16 q = (__bf16)r1;
+        xf[0][j] = p; xf[1][j] = q; xf[2][j] = (__bf16)(r1 - hd_bf(q));
+      }
   }
 
   // Materialise the accumulators HERE.  Left alone, the optimiser sinks an epilogue (bias, LayerNorm, ReLU) into the
@@ -218,54 +235,69 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
     const int total_chunks = np * NCH;
     int gi = 0;                                                                // chunks consumed so far
 
-    auto issue = [&](int ci) {               // stage chunk ci of the stream into buffer ci & 1 (LDS-DMA, 1 KiB per wave-instruction)
+    // Stage chunk ci of the panel stream into buffer ci & 1 by LDS-DMA, 1 KiB per wave-instruction: this wave's piece
+    // number q of NPW (pieces are dealt to the four waves round robin).
+    constexpr int NPW = (HD_KC * NT * 3 + 3) / 4;
+    auto issue_piece = [&](int ci, int q) {
       if (ci >= total_chunks) return;
-      const bf16x8* src = s_list[ci / NCH] + (size_t)(ci % NCH) * CHUNK;
-      bf16x8* dst = s_w + (size_t)(ci & 1) * CHUNK;
-#pragma unroll
-      for (int q = 0; q < (HD_KC * NT * 3 + 3) / 4; ++q) {
-        const int i = w + 4 * q;
-        if (i < HD_KC * NT * 3)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + i * 64 + lane), (lds_ptr_t)(dst + i * 64), 16, 0, 0);
+      const int i = w + 4 * q;
+      if (i < HD_KC * NT * 3) {
+        const bf16x8* src = s_list[ci / NCH] + (size_t)(ci % NCH) * CHUNK;
+        bf16x8* dst = s_w + (size_t)(ci & 1) * CHUNK;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + i * 64 + lane), (lds_ptr_t)(dst + i * 64), 16, 0, 0);
       }
     };
-    issue(0);
+    // the pieces of tile slot t of the chunk's FIRST k-step (so they have the second k-step's time to land)
+    auto issue_slot = [&](int ci, int t) {
+#pragma unroll
+      for (int q = 0; q < NPW; ++q)
+        if (q % NT == t) issue_piece(ci, q);
+    };
+#pragma unroll
+    for (int q = 0; q < NPW; ++q) issue_piece(0, q);
 
     // ---- first layer of a branch from global memory: acc = W0 . X^T ------------------------------------------
-    // rows of chunk c (k-steps 2c, 2c+1) -> this wave's slots of landing buffer `buf`
-    auto issue_x = [&](const float* xrow, int c, int buf) {
+    // rows of chunk c (k-steps 2c, 2c+1) -> this wave's slots of landing buffer `buf`: piece pc of k-step ks
+    auto issue_x = [&](const float* xrow, int c, int buf, int ks, int pc) {
       float4* dst = s_x + (size_t)buf * HD::XBUF + (size_t)w * (HD_KC * 2 * 64);
-#pragma unroll
-      for (int ks = 0; ks < HD_KC; ++ks)
-#pragma unroll
-        for (int pc = 0; pc < 2; ++pc)
-          __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xrow + (c * HD_KC + ks) * 16 + 4 * pc),
-                                           (lds_ptr_t)(dst + (ks * 2 + pc) * 64), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xrow + (c * HD_KC + ks) * 16 + 4 * pc),
+                                       (lds_ptr_t)(dst + (ks * 2 + pc) * 64), 16, 0, 0);
     };
     auto first_layer = [&](f32x16 (&acc)[NT], const float* xb, bool rowmask) {
       const float* xrow = xb + arow * a.ldx + 8 * hh;
       HD::zero(acc);
-      issue_x(xrow, 0, gi & 1);
+#pragma unroll
+      for (int q = 0; q < HD_KC * 2; ++q) issue_x(xrow, 0, gi & 1, q >> 1, q & 1);
 #pragma unroll 1
       for (int c = 0; c < NCH; ++c) {
         // chunk boundary: everything this wave issued has landed (vmcnt), everybody's has (barrier), and nobody still
         // reads the buffers chunk gi + 1 is about to overwrite
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        issue(gi + 1);
-        if (c + 1 < NCH) issue_x(xrow, c + 1, (gi + 1) & 1);
         const bf16x8* wl = s_w + (size_t)(gi & 1) * CHUNK;
         const float4* xl = s_x + (size_t)(gi & 1) * HD::XBUF + (size_t)w * (HD_KC * 2 * 64) + lane;
+        float xs[HD_KC][8];
 #pragma unroll
         for (int ks = 0; ks < HD_KC; ++ks) {
           const float4 x0 = xl[(ks * 2) * 64], x1 = xl[(ks * 2 + 1) * 64];
-          float xs[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+          const float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
 #pragma unroll
-          for (int j = 0; j < 8; ++j) xs[j] = rowmask ? xs[j] : 0.f;         // rows the pooling never wrote count as zero rows
-          bf16x8 xf[3];
-          hd_split8(xs, xf[0], xf[1], xf[2]);
-          HD::kstep(acc, wl + ks * PANEL, xf, lane);
+          for (int j = 0; j < 8; ++j) xs[ks][j] = rowmask ? v[j] : 0.f;      // rows the pooling never wrote count as zero rows
         }
+        bf16x8 xf[3], xg[3];
+        HD::split_part(xs[0], xf, 0, 8);
+        const bool more = c + 1 < NCH;
+        HD::kstep(acc, wl, xf, lane, [&](int t) {         // k-step 0: issue the next chunk, split k-step 1's operand
+          issue_slot(gi + 1, t);
+          if (more && t < HD_KC * 2) issue_x(xrow, c + 1, (gi + 1) & 1, t >> 1, t & 1);
+          if (NT >= 8) HD::split_part(xs[1], xg, t, t + 1);
+          else HD::split_part(xs[1], xg, t * (8 / NT), (t + 1) * (8 / NT));
+        });
+        if (NT < HD_KC * 2 && more) {
+#pragma unroll
+          for (int q = NT; q < HD_KC * 2; ++q) issue_x(xrow, c + 1, (gi + 1) & 1, q >> 1, q & 1);
+        }
+        HD::kstep(acc, wl + PANEL, xg, lane, [](int) {});
         ++gi;
       }
     };
@@ -273,21 +305,32 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
     // ---- a layer whose input is the previous layer's accumulators: acc = W . in (chained panel) --------------
     auto chained_layer = [&](f32x16 (&acc)[NT], const f32x16 (&in)[NT]) {
       HD::zero(acc);
+      bf16x8 xf[3], xg[3];
+      {
+        float xs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xs[j] = in[0][j];
+        HD::split_part(xs, xf, 0, 8);
+      }
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {                    // chunk c = k-steps 2c, 2c+1 = input tile c
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        issue(gi + 1);
         const bf16x8* wl = s_w + (size_t)(gi & 1) * CHUNK;
+        float xs1[8], xs2[8];
 #pragma unroll
-        for (int ks = 0; ks < HD_KC; ++ks) {
-          float xs[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) xs[j] = in[c][8 * ks + j];
-          bf16x8 xf[3];
-          hd_split8(xs, xf[0], xf[1], xf[2]);
-          HD::kstep(acc, wl + ks * PANEL, xf, lane);
-        }
+        for (int j = 0; j < 8; ++j) { xs1[j] = in[c][8 + j]; xs2[j] = in[c + 1 < NCH ? c + 1 : c][j]; }
+        HD::kstep(acc, wl, xf, lane, [&](int t) {          // k-step 0: issue the next chunk, split k-step 1's operand
+          issue_slot(gi + 1, t);
+          if (NT >= 8) HD::split_part(xs1, xg, t, t + 1);
+          else HD::split_part(xs1, xg, t * (8 / NT), (t + 1) * (8 / NT));
+        });
+        HD::kstep(acc, wl + PANEL, xg, lane, [&](int t) {  // k-step 1: split the next chunk's first operand
+          if (c + 1 < NCH) {
+            if (NT >= 8) HD::split_part(xs2, xf, t, t + 1);
+            else HD::split_part(xs2, xf, t * (8 / NT), (t + 1) * (8 / NT));
+          }
+        });
         ++gi;
       }
     };
