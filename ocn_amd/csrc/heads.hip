@@ -78,6 +78,10 @@ struct Heads {
 
   // six cross terms of one k-step of one output tile (smallest first)
   static __device__ __forceinline__ void mma6(f32x16& acc, const bf16x8 (&wf)[3], const bf16x8 (&xf)[3]) {
+#ifdef OCN_X_HD_NOMFMA   /* timing experiment (tools/headsbench.py): everything but the matrix instructions */
+    acc[0] += hd_bf(wf[0][0]) * hd_bf(xf[0][0]) + hd_bf(wf[1][1]) * hd_bf(xf[1][1]) + hd_bf(wf[2][2]) * hd_bf(xf[2][2]);
+    return;
+#endif
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1], xf[1], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0], xf[2], acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2], xf[0], acc, 0, 0, 0);
@@ -203,7 +207,8 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
   float* s_vec = reinterpret_cast<float*>(smem) + 16;
   bf16x8* s_w = reinterpret_cast<bf16x8*>(smem + (size_t)HD::VEC_FLOATS * 4);
   float4* s_x = reinterpret_cast<float4*>(smem + (size_t)HD::VEC_FLOATS * 4 + 2 * (size_t)CHUNK * 16);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);          // scalar: everything decided per wave stays on the scalar unit
   const int r = lane & 31, hh = lane >> 5;
   for (int q = threadIdx.x; q < HD_NVEC * H + 1; q += OCN_BLOCK) s_vec[q] = a.vec[q];
   // where this wave parks a finished branch's share of the output while the next branch needs the registers
@@ -238,30 +243,44 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
     // Stage chunk ci of the panel stream into buffer ci & 1 by LDS-DMA, 1 KiB per wave-instruction: this wave's piece
     // number q of NPW (pieces are dealt to the four waves round robin).
     constexpr int NPW = (HD_KC * NT * 3 + 3) / 4;
-    auto issue_piece = [&](int ci, int q) {
-      if (ci >= total_chunks) return;
+    const unsigned lane16 = (unsigned)lane * 16u;
+    // scalar base of chunk ci in memory (the panel list is read once per chunk, not once per piece)
+    auto chunk_src = [&](int ci) -> const char* {
+      const bf16x8* p = ci < total_chunks ? s_list[ci / NCH] + (size_t)(ci % NCH) * CHUNK : nullptr;
+      const unsigned long long v = (unsigned long long)p;
+      const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+      return (const char*)(((unsigned long long)hi << 32) | lo);
+    };
+    auto issue_piece = [&](const char* src, int ci, int q) {
+#ifndef OCN_X_HD_NOGLDS
+      if (!src) return;
       const int i = w + 4 * q;
       if (i < HD_KC * NT * 3) {
-        const bf16x8* src = s_list[ci / NCH] + (size_t)(ci % NCH) * CHUNK;
         bf16x8* dst = s_w + (size_t)(ci & 1) * CHUNK;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + i * 64 + lane), (lds_ptr_t)(dst + i * 64), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (size_t)i * 1024 + lane16), (lds_ptr_t)(dst + i * 64), 16, 0, 0);
       }
+#endif
     };
     // the pieces of tile slot t of the chunk's FIRST k-step (so they have the second k-step's time to land)
-    auto issue_slot = [&](int ci, int t) {
+    auto issue_slot = [&](const char* src, int ci, int t) {
 #pragma unroll
       for (int q = 0; q < NPW; ++q)
-        if (q % NT == t) issue_piece(ci, q);
+        if (q % NT == t) issue_piece(src, ci, q);
     };
+    {
+      const char* src0 = chunk_src(0);
 #pragma unroll
-    for (int q = 0; q < NPW; ++q) issue_piece(0, q);
+      for (int q = 0; q < NPW; ++q) issue_piece(src0, 0, q);
+    }
 
     // ---- first layer of a branch from global memory: acc = W0 . X^T ------------------------------------------
     // rows of chunk c (k-steps 2c, 2c+1) -> this wave's slots of landing buffer `buf`: piece pc of k-step ks
     auto issue_x = [&](const float* xrow, int c, int buf, int ks, int pc) {
+#ifndef OCN_X_HD_NOGLDS
       float4* dst = s_x + (size_t)buf * HD::XBUF + (size_t)w * (HD_KC * 2 * 64);
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(xrow + (c * HD_KC + ks) * 16 + 4 * pc),
                                        (lds_ptr_t)(dst + (ks * 2 + pc) * 64), 16, 0, 0);
+#endif
     };
     auto first_layer = [&](f32x16 (&acc)[NT], const float* xb, bool rowmask) {
       const float* xrow = xb + arow * a.ldx + 8 * hh;
@@ -287,8 +306,9 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
         bf16x8 xf[3], xg[3];
         HD::split_part(xs[0], xf, 0, 8);
         const bool more = c + 1 < NCH;
+        const char* nsrc = chunk_src(gi + 1);
         HD::kstep(acc, wl, xf, lane, [&](int t) {         // k-step 0: issue the next chunk, split k-step 1's operand
-          issue_slot(gi + 1, t);
+          issue_slot(nsrc, gi + 1, t);
           if (more && t < HD_KC * 2) issue_x(xrow, c + 1, (gi + 1) & 1, t >> 1, t & 1);
           if (NT >= 8) HD::split_part(xs[1], xg, t, t + 1);
           else HD::split_part(xs[1], xg, t * (8 / NT), (t + 1) * (8 / NT));
@@ -320,8 +340,9 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
         float xs1[8], xs2[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { xs1[j] = in[c][8 + j]; xs2[j] = in[c + 1 < NCH ? c + 1 : c][j]; }
+        const char* nsrc = chunk_src(gi + 1);
         HD::kstep(acc, wl, xf, lane, [&](int t) {          // k-step 0: issue the next chunk, split k-step 1's operand
-          issue_slot(gi + 1, t);
+          issue_slot(nsrc, gi + 1, t);
           if (NT >= 8) HD::split_part(xs1, xg, t, t + 1);
           else HD::split_part(xs1, xg, t * (8 / NT), (t + 1) * (8 / NT));
         });

@@ -796,7 +796,7 @@ class CNLinkPredictorOringin(_CNPredictorBase):
 
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
-        st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x)))
+        st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x), adj=adj))
         w = st.weights_cn5(self.innerprod1(st))
         xcn1, xcn2, xij = self._pool(st, w, x)
         return self._heads(x, xcn1, xcn2, xij, getattr(st, "cls", None))
@@ -812,7 +812,7 @@ class CNLinkPredictorbaselearn(_CNPredictorBase):
 
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, args, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
-        st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x)))
+        st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x), adj=adj))
         w = st.weights_cn7(float(args.sum))
         xcn1, xcn2, xij = self._pool(st, w, x)
         return self._heads(x, xcn1, xcn2, xij, getattr(st, "cls", None))

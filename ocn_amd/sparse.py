@@ -244,6 +244,45 @@ class SparseTensor:
         return torch.zeros(self._sizes[1 - dim] if dim in (0, 1) else 0, dtype=v.dtype,
                            device=v.device).index_add_(0, idx, v)
 
+    def mul(self, other: Tensor) -> "SparseTensor":
+        """torch_sparse ``SparseTensor.mul(dense)`` with a broadcastable [1, N] or [M, 1] dense operand
+        (model.py:2272: ``cn1.mul(inv_col_sum.view(1, -1))``): scales the stored values (1.0 where none)."""
+        v = self._value if self._value is not None else torch.ones(self.nnz(), device=self._col.device)
+        other = other if torch.is_tensor(other) else torch.as_tensor(other, device=v.device)
+        if other.dim() == 2 and other.shape[0] == 1 and other.shape[1] == self._sizes[1]:
+            scale = other[0][self._col.to(torch.int64)]
+        elif other.dim() == 2 and other.shape[1] == 1 and other.shape[0] == self._sizes[0]:
+            scale = other[:, 0][self._row64()]
+        elif other.numel() == 1:
+            scale = other.reshape(())
+        else:
+            raise NotImplementedError("SparseTensor.mul: dense operand must broadcast as [1, N], [M, 1] or a scalar")
+        out = SparseTensor(rowptr=self._rowptr, col=self._col, value=v * scale.to(v.dtype), sparse_sizes=self._sizes)
+        return out
+
+    def __mul__(self, other):
+        return self.mul(other)
+
+    def add(self, other: "SparseTensor") -> "SparseTensor":
+        """torch_sparse ``SparseTensor + SparseTensor`` (utils.py:318-321): entries concatenated and coalesced by
+        sum; value-less operands count as ones."""
+        if not isinstance(other, SparseTensor):
+            raise NotImplementedError("SparseTensor + dense")
+        if other._sizes != self._sizes:
+            raise ValueError("SparseTensor.add: sizes differ")
+        dev = self._col.device
+        va = self._value if self._value is not None else torch.ones(self.nnz(), device=dev)
+        vb = other._value if other._value is not None else torch.ones(other.nnz(), device=dev)
+        key = torch.cat([self._row64() * self._sizes[1] + self._col.to(torch.int64),
+                         other._row64() * self._sizes[1] + other._col.to(torch.int64)])
+        uniq, inv = torch.unique(key, return_inverse=True)
+        val = torch.zeros(uniq.numel(), dtype=va.dtype, device=dev).index_add_(0, inv, torch.cat([va, vb.to(va.dtype)]))
+        return SparseTensor(row=torch.div(uniq, self._sizes[1], rounding_mode="floor"), col=uniq % self._sizes[1], value=val,
+                            sparse_sizes=self._sizes, is_sorted=True, trust_data=True)
+
+    def __add__(self, other):
+        return self.add(other)
+
     def to_torch_sparse_coo_tensor(self) -> "CooView":
         return CooView(self)
 

@@ -698,6 +698,29 @@ def test_colsum_exact_on_a_column_longer_than_the_lds_sort(hiplib):
         assert torch.equal(g1.cpu(), xcn1) and torch.equal(g2.cpu(), xcn2)
 
 
+@pytest.mark.parametrize("name", ["cn5", "cn7"])
+def test_predictors_accept_materialised_cn_matrices(case, name):
+    """The reference's own adjoverlap / get_cn1_cn2 hand the predictor explicit [B, N] SparseTensors: those are
+    converted to the flag form (CNState.from_materialized) and score exactly as the lazy handles do."""
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap, get_cn1_cn2
+    H = 64
+    torch.manual_seed(case.seed + 21)
+    x = torch.randn(case.n, H, device=DEV)
+    pred = predictor_dict[name](H, H, 1, 3, 0.0, 0.0, True).to(DEV).eval()
+    with torch.no_grad():
+        pred.innerprod.fill_(0.8)
+    e = case.e.to(DEV)
+    args = SimpleNamespace(sum=2.74)
+    with torch.no_grad():
+        for h1, h2 in ((adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e)), get_cn1_cn2(case.adj, e)):
+            want = pred(x, case.adj, h1, h2, e, args)
+            got = pred(x, case.adj, h1.materialize(), h2.materialize(), e, args)
+            assert torch.equal(got, want)
+            mixed = pred(x, case.adj, h1, h2.materialize(), e, args)
+            assert torch.equal(mixed, want)
+
+
 # ---- valued, non-symmetric adjacencies (what DropAdj hands the encoder in training) -----------
 @pytest.mark.parametrize("kind", ["puregcn", "gcnconv", "pureconv2", "sum"])
 def test_valued_spmm_forward_and_transpose_backward(hiplib, kind):
