@@ -96,6 +96,7 @@ struct Heads {
   // the matrix pipe with them at the chunk boundary (one wave per SIMD: nobody else would fill it).
   template <typename F>
   static __device__ __forceinline__ void kstep(f32x16 (&acc)[NT], const bf16x8* wl, const bf16x8 (&xf)[3], int lane, F&& between) {
+    __builtin_amdgcn_sched_barrier(0);
     bf16x8 wq[2][3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) wq[0][u] = wl[u * 64 + lane];
@@ -105,10 +106,24 @@ struct Heads {
 #pragma unroll
         for (int u = 0; u < 3; ++u) wq[(t + 1) & 1][u] = wl[((t + 1) * 3 + u) * 64 + lane];
       }
-      __builtin_amdgcn_sched_barrier(0);     // keep the prefetch one tile deep: hoisted further, the fragments of a whole
-      mma6(acc[t], wq[t & 1], xf);           // k-step would be live at once
+      mma6(acc[t], wq[t & 1], xf);
       between(t);
     }
+    // The schedule of this region, spelled out: an MFMA occupies the matrix pipe for 32 cycles but the issue port for
+    // 8 only, so every MFMA is followed by the next tile's fragment reads (one per two MFMAs), a slice of the operand
+    // splitting / address arithmetic (VALU), and now and then an LDS-DMA piece.  Left to itself the scheduler issues the
+    // six MFMAs of a tile back to back and everything else in blocks between tiles, where nothing overlaps it.
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);               // the first tile's fragments
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
+        if (m < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // one fragment read of the next tile
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);           // VALU
+        if (m % 3 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // an LDS-DMA piece
+        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);           // SALU (M0, addresses)
+      }
     __builtin_amdgcn_sched_barrier(0);
   }
 
@@ -245,20 +260,21 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
     constexpr int NPW = (HD_KC * NT * 3 + 3) / 4;
     const unsigned lane16 = (unsigned)lane * 16u;
     // scalar base of chunk ci in memory (the panel list is read once per chunk, not once per piece)
+    // (past the end of the stream the last chunk is staged once more, into the buffer nobody reads any more: the main
+    // loops stay free of branches, i.e. one scheduling region per k-step)
     auto chunk_src = [&](int ci) -> const char* {
-      const bf16x8* p = ci < total_chunks ? s_list[ci / NCH] + (size_t)(ci % NCH) * CHUNK : nullptr;
+      const int cc = ci < total_chunks ? ci : total_chunks - 1;
+      const bf16x8* p = s_list[cc / NCH] + (size_t)(cc % NCH) * CHUNK;
       const unsigned long long v = (unsigned long long)p;
       const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
       return (const char*)(((unsigned long long)hi << 32) | lo);
     };
     auto issue_piece = [&](const char* src, int ci, int q) {
 #ifndef OCN_X_HD_NOGLDS
-      if (!src) return;
-      const int i = w + 4 * q;
-      if (i < HD_KC * NT * 3) {
-        bf16x8* dst = s_w + (size_t)(ci & 1) * CHUNK;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (size_t)i * 1024 + lane16), (lds_ptr_t)(dst + i * 64), 16, 0, 0);
-      }
+      int i = w + 4 * q;
+      if ((HD_KC * NT * 3) % 4 != 0) i = i < HD_KC * NT * 3 ? i : HD_KC * NT * 3 - 1;     // (the last piece twice: same bytes)
+      bf16x8* dst = s_w + (size_t)(ci & 1) * CHUNK;
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + (size_t)i * 1024 + lane16), (lds_ptr_t)(dst + i * 64), 16, 0, 0);
 #endif
     };
     // the pieces of tile slot t of the chunk's FIRST k-step (so they have the second k-step's time to land)
@@ -305,17 +321,17 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
         }
         bf16x8 xf[3], xg[3];
         HD::split_part(xs[0], xf, 0, 8);
-        const bool more = c + 1 < NCH;
+        const int cn = c + 1 < NCH ? c + 1 : c;           // (the last chunk's rows once more, into the idle buffer)
         const char* nsrc = chunk_src(gi + 1);
         HD::kstep(acc, wl, xf, lane, [&](int t) {         // k-step 0: issue the next chunk, split k-step 1's operand
           issue_slot(nsrc, gi + 1, t);
-          if (more && t < HD_KC * 2) issue_x(xrow, c + 1, (gi + 1) & 1, t >> 1, t & 1);
+          if (t < HD_KC * 2) issue_x(xrow, cn, (gi + 1) & 1, t >> 1, t & 1);
           if (NT >= 8) HD::split_part(xs[1], xg, t, t + 1);
           else HD::split_part(xs[1], xg, t * (8 / NT), (t + 1) * (8 / NT));
         });
-        if (NT < HD_KC * 2 && more) {
+        if (NT < HD_KC * 2) {
 #pragma unroll
-          for (int q = NT; q < HD_KC * 2; ++q) issue_x(xrow, c + 1, (gi + 1) & 1, q >> 1, q & 1);
+          for (int q = NT; q < HD_KC * 2; ++q) issue_x(xrow, cn, (gi + 1) & 1, q >> 1, q & 1);
         }
         HD::kstep(acc, wl + PANEL, xg, lane, [](int) {});
         ++gi;
