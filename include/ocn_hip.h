@@ -141,6 +141,30 @@ int ocn_walk_rev_offsets(const int64_t* rowptrA, const int64_t* nds, const int64
                          const int64_t* order, int64_t B, int64_t* out /* [B+1] */, void* workspace,
                          void* stream);
 
+/* Small batches of the walk route (B <= ocn_walk_prep_max_batch(): the ppa / citation2 drivers use 2048) — everything in
+ * front of the walk kernels in ONE single-workgroup launch: order[] = the batch rows sorted by (source, batch row); off =
+ * flag offsets (as ocn_edge_offsets); groups = runs of equal source cut into pieces of 64 (g_head[g] = first slot of
+ * group g, g_head[n_groups] = B, meta[0] = n_groups); a group with at least `min_share` members whose targets' rows
+ * sum to at most 2048 entries goes to the shared sweep ocn_cn_walk_group (g_item_off = exclusive scan of its work items,
+ * one per 64 neighbours of the source; 0 for the other groups), every other candidate keeps its per-candidate work items
+ * in chunk_off / rev_off (as ocn_chunk_offsets / ocn_walk_rev_offsets; 0 for candidates of shared groups); cnt1, cnt2,
+ * status[4], scal[4] are cleared.  meta: int32[4] ([1] = the shared sweep's ticket).  rev_off NULL iff nds is.
+ *
+ * ocn_cn_walk_group: the rows N(k), k in N(i), that a candidate (i, j) sweeps for cn2[e,k] = |N(k) n N(j)| are the same
+ * for every candidate with source i (the MRR layout scores 1000 negatives per source, NeighborOverlapCitation2.py:
+ * 248-254): they are swept once per group, each element probed against ONE hash table (node -> 64-bit mask of the
+ * group's targets it neighbours).  Same outputs as ocn_cn_walk_flags, for the candidates of the shared groups; run it
+ * after ocn_cn_walk_flags of the same batch (which handles the others and zeroes wc). */
+int32_t ocn_walk_prep_max_batch(void);
+int ocn_walk_prep(const int64_t* rowptrA, const int64_t* nds /* or NULL */, const int64_t* src, const int64_t* dst,
+                  int64_t B, int32_t min_share, int64_t* order, int64_t* off, int64_t* chunk_off,
+                  int64_t* rev_off /* NULL iff nds is */, int32_t* g_head /* [B+1] */, int64_t* g_item_off /* [B+1] */,
+                  int32_t* meta, int32_t* cnt1, int32_t* cnt2, int32_t* status, int32_t* scal, void* stream);
+int ocn_cn_walk_group(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
+                      const int64_t* order, int64_t B, const int32_t* g_head, const int64_t* g_item_off, int32_t* meta,
+                      const int64_t* off, uint8_t* flags, int32_t* wc, int64_t flags_cap, uint64_t* hist,
+                      int32_t* cnt1, int32_t* cnt2, void* stream);
+
 /* Per-column weights, written IN PLACE over hist (uint64[N][2] -> float[N][4]) as
  *   {w1, t, inv2, 0}: a cn1 entry pools with w1; a union entry whose cn2 value is c (1.0 for the
  *   pattern route, the walk count for the valued route) pools into xcn2 with

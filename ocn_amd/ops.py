@@ -24,6 +24,7 @@ skip_zero_min_share = 0.15       # ... and when fewer than this share of the hea
 skip_zero_backoff = 32           # batches evaluated plainly before the share is probed again
 skip_zero_min_batch = 4096       # below this the extra small launches cost more than the skipped rows save
 walk_two_sided = True            # walk route: sweep each candidate from its cheaper endpoint (needs nds of the adjacency)
+walk_share_min = 2               # walk route, B <= 4096: candidates sharing a source are swept together from this group size on (0 = never)
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 
 
@@ -194,6 +195,8 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     if B > MAX_BATCH:
         raise ValueError(f"candidate batch of {B} edges exceeds the histogram field width ({MAX_BATCH})")
     _mark("begin")
+    if walk and 0 < B <= int(_lib.lib().ocn_walk_prep_max_batch()) and walk_share_min > 0:
+        return _cn_flags_walk_small(rowptrA, colA, src, dst, n_cols, max_deg_a, wsd, nds)
     # processing order: candidates with the same / nearby source node share most of the rows they
     # gather, so visiting them together turns HBM row fetches into L2 hits (outputs stay in batch order)
     order = None
@@ -246,6 +249,48 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
                                       ptr(t2_bitmap), t2_bitmap.shape[1] if t2_bitmap is not None else 0,
                                       ptr(src), ptr(dst), ptr(order), B, n_cols, ptr(off), ptr(flags), cap, ptr(hist),
                                       ptr(cnt1), ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_flags")
+    _mark("cn_flags")
+    return order, off, flags, wc, hist, cnt1, cnt2, status, scal
+
+
+def _cn_flags_walk_small(rowptrA, colA, src, dst, n_cols, max_deg_a, wsd, nds):
+    """Walk route, small batch (the drivers' 2048): one prep launch (ocn_walk_prep), the per-candidate sweeps for
+    candidates with a source of their own, the shared sweep for candidates that share one (ocn_cn_walk_group)."""
+    dev, B = src.device, src.numel()
+    l = _lib.lib()
+    if nds is not None and walk_two_sided:
+        _req(nds, torch.int64, "nds", 1)
+        if nds.numel() != rowptrA.numel() - 1:
+            raise ValueError("nds does not match the adjacency")
+    else:
+        nds = None
+    order = buf(wsd, "order", B, torch.int64, dev)
+    off = buf(wsd, "off", B + 1, torch.int64, dev)
+    chunk_off = buf(wsd, "chunk_off", B + 1, torch.int64, dev)
+    rev_off = buf(wsd, "rev_off", B + 1, torch.int64, dev) if nds is not None else None
+    g_head = buf(wsd, "g_head", B + 1, torch.int32, dev)
+    g_item_off = buf(wsd, "g_item_off", B + 1, torch.int64, dev)
+    meta = buf(wsd, "walk_meta", 4, torch.int32, dev)
+    hist = buf(wsd, "hist", (n_cols, 2), torch.int64, dev)
+    cnt1 = buf(wsd, "cnt1", B, torch.int32, dev)
+    cnt2 = buf(wsd, "cnt2", B, torch.int32, dev)
+    status = buf(wsd, "status", 4, torch.int32, dev)
+    scal = buf(wsd, "scal", 4, torch.int32, dev)
+    check(l.ocn_walk_prep(ptr(rowptrA), ptr(nds), ptr(src), ptr(dst), B, int(walk_share_min), ptr(order), ptr(off),
+                          ptr(chunk_off), ptr(rev_off), ptr(g_head), ptr(g_item_off), ptr(meta), ptr(cnt1), ptr(cnt2),
+                          ptr(status), ptr(scal), stream_ptr()), "ocn_walk_prep")
+    zero_regions([hist])
+    bound = B * max(int(max_deg_a), 0)
+    cap = bound if bound <= FLAGS_NOSYNC_LIMIT else int(off[-1].item())
+    flags = buf(wsd, "flags", max(cap, 1), torch.uint8, dev)
+    wc = buf(wsd, "wc", max(cap, 1), torch.int32, dev)
+    _mark("cn_prep")
+    check(l.ocn_cn_walk_flags(ptr(rowptrA), ptr(colA), ptr(nds), ptr(src), ptr(dst), ptr(order), B, ptr(chunk_off),
+                              ptr(rev_off), ptr(off), int(max_deg_a), ptr(flags), ptr(wc), cap, ptr(hist), ptr(cnt1),
+                              ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_walk_flags")
+    check(l.ocn_cn_walk_group(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(g_head), ptr(g_item_off),
+                              ptr(meta), ptr(off), ptr(flags), ptr(wc), cap, ptr(hist), ptr(cnt1), ptr(cnt2),
+                              stream_ptr()), "ocn_cn_walk_group")
     _mark("cn_flags")
     return order, off, flags, wc, hist, cnt1, cnt2, status, scal
 

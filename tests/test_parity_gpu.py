@@ -532,6 +532,44 @@ def test_walk_route_swept_from_either_endpoint(hiplib, hubs):
         assert picks[:40][i[:40] < 2].all() and not picks[40:80].any()
 
 
+@pytest.mark.parametrize("n_src,per", [(7, 150), (1, 1000), (40, 3)])
+def test_walk_route_shared_source_sweep(hiplib, n_src, per):
+    """Candidates sharing a source (the MRR layout: per source many negatives) are swept together
+    (ocn_cn_walk_group): flags, walk counts, histograms and per-edge counts equal the per-candidate sweeps bit for
+    bit, and the oracle's counts."""
+    from ocn_amd import ops
+    n = 4000
+    oadj = make_graph(n, 9, 300, 17)
+    adj = to_product(oadj, DEV)
+    g = torch.Generator().manual_seed(n_src * 1000 + per)
+    deg = oadj.rowcount()
+    hubs = torch.argsort(deg, descending=True)[: max(n_src // 2, 1)]
+    srcs = torch.cat([hubs, torch.randint(0, n, (n_src - hubs.numel(),), generator=g)])[:n_src]
+    src = srcs.repeat_interleave(per)
+    dst = torch.randint(0, n, (src.numel(),), generator=g)
+    dst[::7] = oadj.col[torch.randint(0, oadj.nnz, (dst[::7].numel(),), generator=g)]       # some high-overlap targets
+    perm = torch.randperm(src.numel(), generator=g)
+    e = torch.stack([src[perm], dst[perm]])
+    B = e.shape[1]
+    assert B <= 4096
+    ed = e.to(DEV)
+    nds = adj.neighbor_degree_sum()
+    keep = ops.walk_share_min
+    try:
+        ops.walk_share_min = 0
+        ref = _walk_raw(adj, ed, nds)
+        ops.walk_share_min = 2
+        got = _walk_raw(adj, ed, nds)
+    finally:
+        ops.walk_share_min = keep
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    oc1, oc2 = O.get_cn1_cn2(oadj, e)
+    assert got[3].tolist() == torch.bincount(oc1.row, minlength=B).tolist()
+    assert got[4].tolist() == torch.bincount(oc2.row, minlength=B).tolist()
+    assert got[2][:, 3].tolist() == torch.zeros(n, dtype=torch.long).index_add_(0, oc2.col, oc2.val.long()).tolist()
+
+
 @pytest.mark.parametrize("name", ["cn5", "cn7"])
 def test_walk_route_predictor_scores(case, name):
     from ocn_amd.model import predictor_dict
