@@ -144,11 +144,11 @@ int ocn_walk_rev_offsets(const int64_t* rowptrA, const int64_t* nds, const int64
 /* Small batches of the walk route (B <= ocn_walk_prep_max_batch(): the ppa / citation2 drivers use 2048) — everything in
  * front of the walk kernels in ONE single-workgroup launch: order[] = the batch rows sorted by (source, batch row); off =
  * flag offsets (as ocn_edge_offsets); groups = runs of equal source cut into pieces of 64 (g_head[g] = first slot of
- * group g, g_head[n_groups] = B, meta[0] = n_groups); a group with at least `min_share` members whose targets' rows
- * sum to at most 2048 entries goes to the shared sweep ocn_cn_walk_group (g_item_off = exclusive scan of its work items,
- * one per 64 neighbours of the source; 0 for the other groups), every other candidate keeps its per-candidate work items
- * in chunk_off / rev_off (as ocn_chunk_offsets / ocn_walk_rev_offsets; 0 for candidates of shared groups); cnt1, cnt2,
- * status[4], scal[4] are cleared.  meta: int32[4] ([1] = the shared sweep's ticket).  rev_off NULL iff nds is.
+ * group g, g_head[n_groups] = B, meta[0] = n_groups); the members of a group whose target has at most 512 neighbours go
+ * to the shared sweep ocn_cn_walk_group if their targets' rows sum to at most 4096 entries — if at least `min_share`
+ * of them do (g_active[slot]; g_item_off = exclusive scan of the group's work items, one per meta[2] x 64 neighbours of the
+ * source) —, every other candidate keeps its per-candidate work items in chunk_off / rev_off (as ocn_chunk_offsets /
+ * ocn_walk_rev_offsets; 0 for the candidates of the shared sweep); cnt1, cnt2, status[4], scal[4] are cleared.  meta: int32[4] ([1] = the shared sweep's ticket).  rev_off NULL iff nds is.
  *
  * ocn_cn_walk_group: the rows N(k), k in N(i), that a candidate (i, j) sweeps for cn2[e,k] = |N(k) n N(j)| are the same
  * for every candidate with source i (the MRR layout scores 1000 negatives per source, NeighborOverlapCitation2.py:
@@ -159,11 +159,12 @@ int32_t ocn_walk_prep_max_batch(void);
 int ocn_walk_prep(const int64_t* rowptrA, const int64_t* nds /* or NULL */, const int64_t* src, const int64_t* dst,
                   int64_t B, int32_t min_share, int64_t* order, int64_t* off, int64_t* chunk_off,
                   int64_t* rev_off /* NULL iff nds is */, int32_t* g_head /* [B+1] */, int64_t* g_item_off /* [B+1] */,
-                  int32_t* meta, int32_t* cnt1, int32_t* cnt2, int32_t* status, int32_t* scal, void* stream);
+                  int32_t* g_active /* [B]: slot goes to the shared sweep */, int32_t* meta, int32_t* cnt1,
+                  int32_t* cnt2, int32_t* status, int32_t* scal, void* stream);
 int ocn_cn_walk_group(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
-                      const int64_t* order, int64_t B, const int32_t* g_head, const int64_t* g_item_off, int32_t* meta,
-                      const int64_t* off, uint8_t* flags, int32_t* wc, int64_t flags_cap, uint64_t* hist,
-                      int32_t* cnt1, int32_t* cnt2, void* stream);
+                      const int64_t* order, int64_t B, const int32_t* g_head, const int64_t* g_item_off,
+                      const int32_t* g_active, int32_t* meta, const int64_t* off, uint8_t* flags, int32_t* wc,
+                      int64_t flags_cap, uint64_t* hist, int32_t* cnt1, int32_t* cnt2, void* stream);
 
 /* Per-column weights, written IN PLACE over hist (uint64[N][2] -> float[N][4]) as
  *   {w1, t, inv2, 0}: a cn1 entry pools with w1; a union entry whose cn2 value is c (1.0 for the

@@ -38,8 +38,8 @@ SIGNATURES = {
                                     _P, _P]),
     "ocn_neighbor_degree_sum": (c_int32, [_P, _P, c_int64, _P, _P]),
     "ocn_walk_prep_max_batch": (c_int32, []),
-    "ocn_walk_prep": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    "ocn_cn_walk_group": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "ocn_walk_prep": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ocn_cn_walk_group": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "ocn_walk_rev_offsets": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
     "ocn_cn_weights_cn5": (c_int32, [_P, c_int64, _P, _P, c_int32, _P, _P]),
     "ocn_cn5_column_stats": (c_int32, [_P, c_int64, _P, _P]),

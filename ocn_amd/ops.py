@@ -270,6 +270,7 @@ def _cn_flags_walk_small(rowptrA, colA, src, dst, n_cols, max_deg_a, wsd, nds):
     rev_off = buf(wsd, "rev_off", B + 1, torch.int64, dev) if nds is not None else None
     g_head = buf(wsd, "g_head", B + 1, torch.int32, dev)
     g_item_off = buf(wsd, "g_item_off", B + 1, torch.int64, dev)
+    g_active = buf(wsd, "g_active", B, torch.int32, dev)
     meta = buf(wsd, "walk_meta", 4, torch.int32, dev)
     hist = buf(wsd, "hist", (n_cols, 2), torch.int64, dev)
     cnt1 = buf(wsd, "cnt1", B, torch.int32, dev)
@@ -277,8 +278,8 @@ def _cn_flags_walk_small(rowptrA, colA, src, dst, n_cols, max_deg_a, wsd, nds):
     status = buf(wsd, "status", 4, torch.int32, dev)
     scal = buf(wsd, "scal", 4, torch.int32, dev)
     check(l.ocn_walk_prep(ptr(rowptrA), ptr(nds), ptr(src), ptr(dst), B, int(walk_share_min), ptr(order), ptr(off),
-                          ptr(chunk_off), ptr(rev_off), ptr(g_head), ptr(g_item_off), ptr(meta), ptr(cnt1), ptr(cnt2),
-                          ptr(status), ptr(scal), stream_ptr()), "ocn_walk_prep")
+                          ptr(chunk_off), ptr(rev_off), ptr(g_head), ptr(g_item_off), ptr(g_active), ptr(meta), ptr(cnt1),
+                          ptr(cnt2), ptr(status), ptr(scal), stream_ptr()), "ocn_walk_prep")
     zero_regions([hist])
     bound = B * max(int(max_deg_a), 0)
     cap = bound if bound <= FLAGS_NOSYNC_LIMIT else int(off[-1].item())
@@ -289,7 +290,7 @@ def _cn_flags_walk_small(rowptrA, colA, src, dst, n_cols, max_deg_a, wsd, nds):
                               ptr(rev_off), ptr(off), int(max_deg_a), ptr(flags), ptr(wc), cap, ptr(hist), ptr(cnt1),
                               ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_walk_flags")
     check(l.ocn_cn_walk_group(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(g_head), ptr(g_item_off),
-                              ptr(meta), ptr(off), ptr(flags), ptr(wc), cap, ptr(hist), ptr(cnt1), ptr(cnt2),
+                              ptr(g_active), ptr(meta), ptr(off), ptr(flags), ptr(wc), cap, ptr(hist), ptr(cnt1), ptr(cnt2),
                               stream_ptr()), "ocn_cn_walk_group")
     _mark("cn_flags")
     return order, off, flags, wc, hist, cnt1, cnt2, status, scal
