@@ -62,6 +62,8 @@ __device__ __forceinline__ i64 wgp_scan(T* v, int n, i64* tmp) {
 }
 
 #define WG_TAB (2 * WG_MAX_B)         /* source hash table of the prep kernel */
+#define WG_SHARE_OVERHEAD 32768        /* fixed cost of a shared group (table build, counters), in swept elements */
+#define WG_OWN_OVERHEAD 16384          /* fixed cost of a candidate's own sweep (its work items' set-up), likewise */
 #define WG_BIG 512                    /* a target with more neighbours than this always keeps its own sweep */
 
 __global__ __launch_bounds__(WG_THREADS) void walk_prep_kernel(
@@ -135,10 +137,33 @@ __global__ __launch_bounds__(WG_THREADS) void walk_prep_kernel(
   }
   if (t == 0) g_head[ng] = B;
   __syncthreads();
-  for (int s = t; s < B; s += WG_THREADS)
-    if (s_dj[s] <= WG_BIG) { atomicAdd(&s_gsum[s_gid[s]], s_dj[s]); atomicAdd(&s_gcnt[s_gid[s]], 1); }
+  // ... and the sweep shared by the group (the rows of N(i) once: nds[i] elements, plus building the table) must be
+  // cheaper than its members' own sweeps, each from its cheaper endpoint: random low-degree targets are swept from
+  // the target's side for next to nothing, and a group of them gains little from sharing.
+  int32_t* s_gcost = reinterpret_cast<int32_t*>(s_a);                  // [WG_MAX_B] members' own cost, in units of 64 elements
+  for (int g = t; g < (int)ng; g += WG_THREADS) s_gcost[g] = 0;
   __syncthreads();
-  for (int g = t; g < (int)ng; g += WG_THREADS) s_gel[g] = (s_gcnt[g] >= min_share && s_gsum[g] <= WG_KEYCAP) ? 1 : 0;
+  for (int s = t; s < B; s += WG_THREADS)
+    if (s_dj[s] <= WG_BIG) {
+      atomicAdd(&s_gsum[s_gid[s]], s_dj[s]);
+      atomicAdd(&s_gcnt[s_gid[s]], 1);
+      if (nds) {
+        const i64 e = s_ord[s];
+        const i64 i = src[e], j = dst[e];
+        const i64 di = rowptrA[i + 1] - rowptrA[i], dj = s_dj[s];
+        const i64 own = walk_reverse(nds, i, j, di, dj) ? 2 * nds[j] + di * ((dj + WALK_REV_CHUNK - 1) / WALK_REV_CHUNK) + 2 * di : nds[i];
+        atomicAdd(&s_gcost[s_gid[s]], (int)min((i64)(1 << 24), ((own + WG_OWN_OVERHEAD) >> 6) + 1));
+      }
+    }
+  __syncthreads();
+  for (int g = t; g < (int)ng; g += WG_THREADS) {
+    bool ok = s_gcnt[g] >= min_share && s_gsum[g] <= WG_KEYCAP;
+    if (ok && nds) {
+      const i64 i = src[s_ord[g_head[g]]];
+      ok = ((nds[i] + WG_SHARE_OVERHEAD) >> 6) < (i64)s_gcost[g];
+    }
+    s_gel[g] = ok ? 1 : 0;
+  }
   __syncthreads();
   for (int s = t; s < B; s += WG_THREADS) s_act[s] = (s_dj[s] <= WG_BIG && s_gel[s_gid[s]]) ? 1 : 0;
   __syncthreads();
