@@ -840,11 +840,14 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_wave_kernel(
   if (g == 0) pool_store<LPE, NV>(out_row ? out_row[e] : e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
 }
 
-// One workgroup per batch row whose source row is longer than LONG_ROW (hub sources): the 1024/LPE
-// lane groups pool contiguous segments, partial sums meet in LDS and are added in segment order.
-// LONG_THREADS: 1024 for small batches (few hub rows, each as parallel as a workgroup gets), 256 for
-// large ones (one workgroup is launched per batch row and all but the hub rows' leave at once: 32 768
-// x 16 waves of that cost the ddi shape 0.2 ms).
+// One workgroup per batch row whose source row is longer than LONG_ROW (hub sources; 8 403 neighbours at the citation2
+// shape).  The sum stays the reference's: strictly sequential in ascending column order.  What a workgroup adds is
+// the memory parallelism: per round of LONG_THREADS positions the live entries are compacted by rank, ALL lane groups
+// fetch their embedding rows into an LDS slab (LONG_SLAB_BYTES per sub-round), and lane group 0 alone accumulates
+// them in rank order — bit for bit the sum cn_gather_kernel forms for a short row.
+// LONG_THREADS: 1024 for small batches (few hub rows, each as parallel as a workgroup gets), 256 for large ones (one
+// workgroup is launched per batch row and all but the hub rows' leave at once).
+#define LONG_SLAB_BYTES 32768
 template <int LPE, int NV, int LONG_THREADS>
 __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
@@ -853,49 +856,73 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
     float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij,
     const i64* __restrict__ out_row) {   // out_row[batch row] = output row (class-major heads), or NULL
-  constexpr int NG = LONG_THREADS / LPE;    // lane groups per workgroup
-  __shared__ float4 s_part[NG][2][LPE * NV];
+  constexpr int NG = LONG_THREADS / LPE;                       // lane groups per workgroup
+  constexpr int ROWQ = LPE * NV;                               // float4 per embedding row
+  constexpr int SLAB = LONG_SLAB_BYTES / (16 * ROWQ);          // rows per sub-round
+  constexpr int WAVES = LONG_THREADS / OCN_WAVE;
+  __shared__ float4 s_x[SLAB][ROWQ];
+  __shared__ int32_t s_k[LONG_THREADS];
+  __shared__ float2 s_w[LONG_THREADS];
+  __shared__ int s_wcnt[WAVES];
   const i64 e = blockIdx.x;
   const i64 i = src[e], j = dst[e];
   const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
   if (da <= LONG_ROW) return;               // whole workgroup leaves together
-  const int lane = threadIdx.x & 63;
-  const int gl = lane % LPE;
-  const int gbase = lane - gl;
-  const int g = threadIdx.x / LPE;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int gl = threadIdx.x % LPE, g = threadIdx.x / LPE;
+  const i64 base = off[e];
   const float4* h4 = reinterpret_cast<const float4*>(h);
   const i64 rowq = H >> 2;
-  i64 seg = (da + NG - 1) / NG;
-  seg = ((seg + LPE - 1) / LPE) * LPE;
-  const i64 pb = (i64)g * seg < da ? (i64)g * seg : da;
-  const i64 pe = pb + seg < da ? pb + seg : da;
   float4 acc1[NV], acc2[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // hub rows are few and long: more gathers in flight per lane group where the registers allow
-  pool_range<LPE, NV, (LPE * NV <= (LONG_THREADS == 1024 ? 8 : 32) ? 8 : 4)>(pb, pe, a0, off[e], gl, gbase, colA, flags, wc,
-                                                                       weights, h4, rowq, acc1, acc2);
+  for (i64 p0 = 0; p0 < da; p0 += LONG_THREADS) {
+    const i64 p = p0 + threadIdx.x;
+    int32_t k = 0, cv = 1;
+    unsigned f = 0;
+    if (p < da) { k = colA[a0 + p]; f = flags[base + p]; if (wc) cv = wc[base + p]; }
+    float wa = 0.f, wb = 0.f;
+    if (f) entry_weights(f, weights[k], (float)cv, wa, wb);
+    const bool need = (wa != 0.f) | (wb != 0.f);
+    const unsigned long long m = __ballot(need);
+    if (lane == 0) s_wcnt[wv] = __popcll(m);
+    __syncthreads();
+    int before = 0, n = 0;
 #pragma unroll
-  for (int v = 0; v < NV; ++v) {
-    s_part[g][0][gl + v * LPE] = acc1[v];
-    s_part[g][1][gl + v * LPE] = acc2[v];
-  }
-  __syncthreads();
-  if (g == 0) {
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      float4 t1 = s_part[0][0][gl + v * LPE], t2 = s_part[0][1][gl + v * LPE];
-#pragma unroll 1
-      for (int q = 1; q < NG; ++q) {
-        const float4 u1 = s_part[q][0][gl + v * LPE], u2 = s_part[q][1][gl + v * LPE];
-        t1.x = __fadd_rn(t1.x, u1.x); t1.y = __fadd_rn(t1.y, u1.y); t1.z = __fadd_rn(t1.z, u1.z); t1.w = __fadd_rn(t1.w, u1.w);
-        t2.x = __fadd_rn(t2.x, u2.x); t2.y = __fadd_rn(t2.y, u2.y); t2.z = __fadd_rn(t2.z, u2.z); t2.w = __fadd_rn(t2.w, u2.w);
-      }
-      acc1[v] = t1;
-      acc2[v] = t2;
+    for (int q = 0; q < WAVES; ++q) {
+      const int c = s_wcnt[q];
+      if (q < wv) before += c;
+      n += c;
     }
-    pool_store<LPE, NV>(out_row ? out_row[e] : e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
+    if (need) {                               // compaction by rank: ascending position = ascending column
+      const int rank = before + __popcll(m & ((1ull << lane) - 1ull));
+      s_k[rank] = k;
+      s_w[rank] = make_float2(wa, wb);
+    }
+    __syncthreads();
+    for (int r0 = 0; r0 < n; r0 += SLAB) {
+      const int nr = n - r0 < SLAB ? n - r0 : SLAB;
+      for (int r = g; r < nr; r += NG) {
+        const float4* row = h4 + (i64)s_k[r0 + r] * rowq + gl;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) s_x[r][gl + v * LPE] = row[v * LPE];
+      }
+      __syncthreads();
+      if (g == 0) {
+        for (int r = 0; r < nr; ++r) {
+          const float2 wr = s_w[r0 + r];
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            const float4 xs = s_x[r][gl + v * LPE];
+            axpy4(acc1[v], wr.x, xs);
+            axpy4(acc2[v], wr.y, xs);
+          }
+        }
+      }
+      __syncthreads();
+    }
   }
+  if (g == 0) pool_store<LPE, NV>(out_row ? out_row[e] : e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
 }
 
 // cn6 pooling: three pooled vectors.  flagsA carries the cn1 / cn2 bits, flagsB's bit 0 the cn3 bit (two

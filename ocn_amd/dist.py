@@ -18,6 +18,13 @@ import torch.distributed as dist
 from torch import Tensor
 
 
+force_collectives = False        # tests: run the collectives even with one rank (a one-GPU box can then exercise the RCCL path)
+
+
+def _solo(group) -> bool:
+    return (not (dist.is_available() and dist.is_initialized())) or (dist.get_world_size(group) == 1 and not force_collectives)
+
+
 def shard_bounds(total: int, world: int) -> List[Tuple[int, int]]:
     """Contiguous, balanced slices (first ``total % world`` ranks get one extra edge)."""
     base, rem = divmod(total, world)
@@ -39,7 +46,7 @@ def allreduce_hist(hist: Tensor, group=None, valued: bool = True) -> Tensor:
     """In-place sum of the packed per-column histograms (int64 [N, 2]: integer fields, so the sum is
     exact and order-independent) over the edge shards.  ``valued=False`` (pattern route: the second
     word, the walk-count sums, is all zero) moves only the packed word: half the bytes on the wire."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if not _solo(group):
         buf = hist if valued else hist[:, 0].contiguous()
         if _host_staged(buf, group):
             tmp = buf.cpu()
@@ -59,7 +66,7 @@ def ring_colsum(run, n_cols: int, device, group=None) -> Tensor:
     (``run(init)`` = ocn_cn_colsum_exact with ``s2_init``), the last rank holds the single-device result and
     broadcasts it.  One [N] fp32 vector per hop — serial in the world size by construction, which is the price of
     the reference's summation order; a fresh model (innerprod == 0) never takes this path."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _solo(group):
         return run(None)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     ranks = [dist.get_global_rank(group, r) if group is not None else r for r in range(world)]
@@ -89,7 +96,7 @@ def check_global_batch(total: int) -> None:
 
 def gather_scores(local: Tensor, total: int, group=None) -> Tensor:
     """All-gather the per-edge scores of every shard back into batch order: [total, C]."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _solo(group):
         return local
     world = dist.get_world_size(group)
     bounds = shard_bounds(total, world)

@@ -127,6 +127,16 @@ def _values(adj: SparseTensor):
     return None if v is None else v.to(torch.float32)
 
 
+def _lin_eval(lin: nn.Linear, x: Tensor, relu: bool = False) -> Tensor:
+    """An encoder's dense ``X Wᵀ (+ b)`` (GCNConv.lin, PureConv2.lin, xemb: model.py:58-68, 98-113, 253-262): under
+    no_grad on the library's own MFMA Linear kernel (widths 32..256, K a multiple of 16), else the torch module."""
+    if (not torch.is_grad_enabled() and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+            and ops.linear_ok(x.contiguous(), lin.weight)):
+        return ops.linear(x.contiguous(), lin.weight, lin.bias, None, relu)
+    y = lin(x)
+    return torch.relu_(y) if relu else y
+
+
 class PureConv(nn.Module):
     """model.py:32-55 — parameter-free aggregation; ``gcn`` = n ⊙ (A(n ⊙ x) + n ⊙ x), n = (1+deg)^-½."""
     aggr: Final[str]
@@ -165,7 +175,7 @@ class GCNConv(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
 
     def forward(self, x, adj_t: SparseTensor):
-        x = self.lin(x).contiguous()
+        x = _lin_eval(self.lin, x).contiguous()
         if self.normalize:
             dinv = ops.deg_rsqrt(adj_t._rowptr, 1.0, val=_values(adj_t))   # degree of A + I (A has no self loops)
             out = _spmm(adj_t, x, pre=dinv, mode="sum", edge_scale=True,
@@ -212,6 +222,8 @@ class PureConv2(nn.Module):
         elif self.aggr == "gcn":
             norm = ops.deg_rsqrt(adj_t._rowptr, 1.0, val=_values(adj_t))
             x = _spmm(adj_t, x, pre=norm, mode="sum", edge_scale=True)
+        if isinstance(self.lin, nn.Sequential) and not self.training:
+            return _lin_eval(self.lin[0], x, relu=True)                  # Linear(no bias) + ReLU in one launch
         return self.lin(x)
 
 
@@ -293,7 +305,11 @@ class _Encoder(nn.Module):
                     self.lins.append(nn.Identity())
 
     def forward(self, x, adj_t):
-        x = self.xemb(x)
+        if (not self.training and not torch.is_grad_enabled() and torch.is_tensor(x) and x.is_cuda
+                and x.dtype == torch.float32 and x.dim() == 2):
+            x = _seq_eval(self.xemb, x)                                  # eval: Dropouts vanish, the input Linear on the MFMA kernel
+        else:
+            x = self.xemb(x)
         jkx = []
         for i, conv in enumerate(self.convs):
             a = self.adjdrop(adj_t) if self._use_adjdrop else adj_t

@@ -71,3 +71,51 @@ def test_two_ranks_on_one_gpu_equal_single_process(hiplib):
         for k in single:
             assert out[k].shape == tuple(single[k].shape)
             assert torch.equal(torch.from_numpy(out[k]), single[k]), f"rank {rank} {k}: sharded scores differ from the single-device batch"
+
+
+def _rccl_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        from types import SimpleNamespace
+        import ocn_amd.dist as D
+        from ocn_amd.utils import adjoverlap
+        dev, adj, adj2, edges, h, preds = _setup()
+        args = SimpleNamespace(sum=2.74)
+        D.force_collectives = True
+        ok = {}
+        with torch.no_grad():
+            for k, p in preds.items():
+                single = p(h, adj, adjoverlap(adj, adj, edges), adjoverlap(adj, adj2, edges), edges, args)
+                p.set_edge_sharding(None, enabled=True)          # force the collectives: all-reduce, ring, all-gather on RCCL
+                try:
+                    from ocn_amd.dist import gather_scores
+                    loc = p(h, adj, adjoverlap(adj, adj, edges), adjoverlap(adj, adj2, edges), edges, args)
+                    out = gather_scores(loc, edges.shape[1])
+                finally:
+                    p.set_edge_sharding(None, enabled=False)
+                ok[k] = bool(torch.equal(out, single))
+        t = torch.ones(1 << 20, device=dev)
+        dist.all_reduce(t)
+        ok["allreduce"] = bool((t == 1).all())
+        q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_backend_single_rank(hiplib):
+    """The production backend ("nccl" = RCCL) with one rank on the test box's GPU: the library initialises, the
+    histogram all-reduce / S2 ring / score all-gather code paths of ocn_amd.dist run on device tensors (no host
+    staging) and leave the scores bit-identical.  (More ranks need more GPUs: the driver's scaling run.)"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    ok = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    assert all(ok.values()), ok
