@@ -289,6 +289,24 @@ int ocn_spgemm_pattern_fill(const int64_t* rowptrA, const int32_t* colA, int64_t
                             const int64_t* rowptrB, const int32_t* colB, int64_t n_colsB,
                             const int64_t* rowptrC, int32_t* colC, void* stream);
 
+/* The block route of utils.block_matrix_multiply (utils.py:287-323; the drivers' --adj2byblock, ogbl-ddi): A as a dense
+ * 0/1 int8 matrix (ocn_dense_from_csr: dense[r][c] and its transpose, row stride ld bytes, ld a multiple of 64 >= n, both
+ * ZERO on entry), each (row block, column block) of the reference's tile loop multiplied on the integer matrix cores
+ * (v_mfma_i32_32x32x32_i8; the entries are walk counts, exact in int32) and the non-zero pattern OR-ed into bit rows
+ * (ocn_dense_block_mm_bits: rows [r0, r1) x columns [c0, c1), block starts multiples of 32, K = inner dimension).
+ * fold != 0 writes the block at its block-LOCAL position — the reference adds SparseTensor.from_dense(block), whose
+ * indices are block-local, without the block's offset (utils.py:318-321): every block then lands on the
+ * top-left corner; fold == 0 places it where it belongs (the intended A^2).  ocn_bitrows_count / _fill turn bit rows
+ * into CSR (columns ascending). */
+int ocn_dense_from_csr(const int64_t* rowptr, const int32_t* col, int64_t n, int64_t ld, int8_t* dense, int8_t* denseT,
+                       void* stream);
+int ocn_dense_block_mm_bits(const int8_t* A, const int8_t* Bt, int64_t ld, int64_t K, int32_t r0, int32_t r1, int32_t c0,
+                            int32_t c1, int32_t fold, uint32_t* bits, int64_t bm_stride_words, void* stream);
+int ocn_bitrows_count(const uint32_t* bits, int64_t bm_stride_words, int64_t n_rows, int64_t n_cols, int32_t* row_count,
+                      void* stream);
+int ocn_bitrows_fill(const uint32_t* bits, int64_t bm_stride_words, int64_t n_rows, int64_t n_cols, const int64_t* rowptr,
+                     int32_t* col, void* stream);
+
 /* Glue for head layouts the fused Linear kernel below does not cover (widths outside 32..256, training
  * mode; model.py:2203-2235, 2429-2437): y = LayerNorm(x) (eps, affine gamma/beta) followed by ReLU when `relu` != 0,
  * one pass over [rows][H] (replaces nn.LayerNorm + Dropout(eval) + nn.ReLU); and the branch mix

@@ -545,6 +545,38 @@ def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int):
     return rowptrC, colC, bitmap
 
 
+dense_adj2_max_nodes = 32768      # block route: A as a dense int8 matrix (n^2 bytes, twice) up to this many nodes
+
+
+@_on_device
+def dense_block_adj2(rowptr: Tensor, col: Tensor, n: int, block_size: int, fold: bool = False):
+    """Pattern of A·A by the reference's block loop on the integer matrix cores (ocn_hip.h: ocn_dense_block_mm_bits).
+    Returns (rowptrC, colC, bit rows [n, words] int32)."""
+    _req(rowptr, torch.int64, "rowptr", 1); _req(col, torch.int32, "col", 1)
+    if block_size <= 0 or block_size % 32:
+        raise ValueError("block_size must be a positive multiple of 32 for the dense block route")
+    l = _lib.lib()
+    dev = col.device
+    ld = (n + 63) // 64 * 64
+    dense = torch.zeros(ld, ld, dtype=torch.int8, device=dev)
+    denseT = torch.zeros(ld, ld, dtype=torch.int8, device=dev)
+    check(l.ocn_dense_from_csr(ptr(rowptr), ptr(col), n, ld, ptr(dense), ptr(denseT), stream_ptr()), "ocn_dense_from_csr")
+    words = (n + 31) // 32
+    bits = torch.zeros(n, words, dtype=torch.int32, device=dev)
+    for r0 in range(0, n, block_size):                   # the tile loop of utils.py:305-321
+        for c0 in range(0, n, block_size):
+            check(l.ocn_dense_block_mm_bits(ptr(dense), ptr(denseT), ld, n, r0, min(r0 + block_size, n), c0, min(c0 + block_size, n),
+                                            int(fold), ptr(bits), words, stream_ptr()), "ocn_dense_block_mm_bits")
+    cnt = torch.empty(n, dtype=torch.int32, device=dev)
+    check(l.ocn_bitrows_count(ptr(bits), words, n, n, ptr(cnt), stream_ptr()), "ocn_bitrows_count")
+    rowptrC = scan_i32(cnt)
+    nnz = int(rowptrC[-1].item())
+    colC = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
+    if nnz:
+        check(l.ocn_bitrows_fill(ptr(bits), words, n, n, ptr(rowptrC), ptr(colC), stream_ptr()), "ocn_bitrows_fill")
+    return rowptrC, colC, bits
+
+
 @_on_device
 def rows_ln_relu(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu: bool, inplace: bool = False) -> Tensor:
     """LayerNorm over the last dim of a [rows, H] fp32 matrix, optionally followed by ReLU."""

@@ -288,6 +288,29 @@ def test_oracle_vectors_regression(hiplib):
                 assert g[0].cpu().tolist() == pytest.approx(want["xcn3_row0"], rel=1e-5, abs=(1e-6 if ip == 0.0 else 1e-5 * scale))
 
 
+@pytest.mark.parametrize("n,avg,bs", [(300, 40, 64), (1000, 120, 256), (2100, 30, 1024)])
+def test_block_route_adj2_on_the_integer_matrix_cores(hiplib, n, avg, bs):
+    """utils.block_matrix_multiply (utils.py:287-323) as dense int8 MFMA block products: the offset-correct pattern equals
+    the sparse A² (and the oracle's block loop), the bit rows match the CSR, and fold_quirk=True reproduces the
+    reference's block-local accumulation as the oracle's switch does."""
+    from ocn_amd.utils import block_matrix_multiply
+    oadj = make_graph(n, avg, min(n - 1, 6 * avg), n + bs)
+    adj = to_product(oadj, DEV)
+    want = O.adj2_by_block(oadj, bs)
+    got = block_matrix_multiply(adj, bs)
+    assert got.nnz() == want.nnz and spm_equal(got, want)
+    assert spm_equal(got, O.adj2_sparse(oadj)) and spm_equal(product_adj2(adj), want)
+    bits = got._bitmap
+    r, c, _ = got.coo()
+    probe = (bits[r, c >> 5] >> (c & 31).to(torch.int32)) & 1
+    assert bool(probe.all()) and int(torch.ops.aten.bitwise_and(bits, -1).ne(0).sum()) > 0
+    pop = sum(((bits >> k) & 1).sum() for k in range(32))
+    assert int(pop) == got.nnz()
+    fold = block_matrix_multiply(adj, bs, fold_quirk=True)
+    wantf = O.adj2_by_block(oadj, bs, fold_quirk=True)
+    assert fold.nnz() == wantf.nnz and spm_equal(fold, wantf)
+
+
 # ---- edge cases ---------------------------------------------------------------------------
 def test_edge_cases(hiplib):
     from ocn_amd.model import predictor_dict
