@@ -466,34 +466,43 @@ def main():
             dom = max((k for k in ("cn_flags", "cn_gather", "linear") if k in stages), key=lambda k: per_step[k])
             roof_hbm = roofs.get("cn_gather")
             if dom == "linear":
-                # f32 FLOPs of the Linear layers per launch.  With the zero-row skipping of the heads the
-                # launches cover only part of the batch (device-side row ranges): count the rows they do.
+                # MFMA work of the MLP heads per launch.  The fused kernel (ocn_heads_fused) multiplies a row by 8
+                # H x H panels (the reference's 9 Linear(H,H): the last layer of each branch is folded into lin's
+                # Linear offline, model._fused_pack) and skips, per 128-row tile of the class-major order, the pooled
+                # branches whose input is all zero; every f32 product is six bf16 MFMA cross terms.
                 launches_per_step = stages["linear"]["launches"] / sampled
-                fl = timer.flops.get("linear", 0.0) / stages["linear"]["launches"]
-                skip = getattr(pred, "_skip_state", None)
                 Bm = mines[0].shape[1]
-                skipping = bool(ops.skip_zero_rows and skip is not None and skip["off"] == 0
-                                and Bm >= ops.skip_zero_min_batch and pred._heads_plan(H) is not None)
-                if skipping:
-                    n_cn1, n_any = ab["n_cn1"], ab["n_any"]
-                    n_b = n_any if pred._xcn2_on_union else ab["n_cn2"]
-                    sx_layers = len(pred._heads_plan(H)[2])
-                    lin_layers = sum(1 for m in pred.lin if isinstance(m, torch.nn.Linear) and m.out_features == H)
-                    executed = 2.0 * H * H * (2 * n_cn1 + 2 * n_b + sx_layers * Bm + lin_layers * Bm) + 2.0 * (2 * H) * H * n_any
-                    fl = executed / launches_per_step
                 t = stages["linear"]["ms"] * 1e-3
-                roof = dict(bound="mfma", kernel="linear_bf16x6_kernel", achieved=fl / t / 1e12,
-                            peak=F32_MFMA_PEAK / 1e12, unit="TFLOP/s", frac=fl / t / F32_MFMA_PEAK,
-                            traffic=pmc("linear_bf16x6_kernel"),
-                            algorithmic_flops_per_launch=fl, avg_launch_ms=stages["linear"]["ms"],
+                fused = bool(ops.fused_heads and getattr(pred, "_fused_plan", lambda H: None)(H) is not None)
+                ref_fl = timer.flops.get("linear", 0.0) / stages["linear"]["launches"]
+                skip = getattr(pred, "_skip_state", None)
+                skipping = bool(ops.skip_zero_rows and skip is not None and skip["off"] == 0 and Bm >= ops.skip_zero_min_batch)
+                n_cn1, n_any = ab["n_cn1"], ab["n_any"]
+                n_b = n_any if pred._xcn2_on_union else ab["n_cn2"]
+                if fused:
+                    rows_a, rows_b = (n_cn1, n_b) if skipping else (Bm, Bm)
+                    f32_fl = 2.0 * H * H * (3 * rows_a + 3 * rows_b + 2 * Bm) / launches_per_step
+                    kern = "heads_fused_kernel"
+                else:
+                    f32_fl = ref_fl
+                    if skipping and pred._heads_plan(H) is not None:
+                        sx_layers = len(pred._heads_plan(H)[2])
+                        lin_layers = sum(1 for m in pred.lin if isinstance(m, torch.nn.Linear) and m.out_features == H)
+                        f32_fl = (2.0 * H * H * (2 * n_cn1 + 2 * n_b + sx_layers * Bm + lin_layers * Bm)
+                                  + 2.0 * (2 * H) * H * n_any) / launches_per_step
+                    kern = "linear_bf16x6_kernel"
+                roof = dict(bound="mfma", kernel=kern, achieved=6 * f32_fl / t / 1e12, peak=BF16_MFMA_PEAK / 1e12,
+                            unit="TFLOP/s", frac=6 * f32_fl / t / BF16_MFMA_PEAK, traffic=pmc(kern),
+                            algorithmic_flops_per_launch=6 * f32_fl, avg_launch_ms=stages["linear"]["ms"],
                             launches_per_step=launches_per_step,
-                            executed_bf16_tflops=6 * fl / t / 1e12, executed_frac_of_bf16_peak=6 * fl / t / BF16_MFMA_PEAK,
+                            f32_equivalent_tflops=f32_fl / t / 1e12, f32_mfma_peak_tflops=F32_MFMA_PEAK / 1e12,
+                            reference_head_f32_flops_per_step=2.0 * H * H * 9 * Bm + 2.0 * H * Bm,
                             skipped_zero_rows=skipping,
-                            note="per-launch averages over the Linear launches of a step (" + head_layout(pred) + "; less "
-                                 "the rows whose pooled input is all zero when skipped_zero_rows); f32 Linear evaluated "
-                                 "as six bf16 MFMA cross terms: achieved/peak are the algorithmic f32 FLOPs against "
-                                 "the dense f32 MFMA peak; executed_* count the bf16 MFMAs actually issued against "
-                                 "the dense bf16 peak")
+                            note="dtype f32 evaluated on the bf16 matrix cores: every f32 product is six bf16 MFMA cross "
+                                 "terms (bf16x6 split), so achieved/peak count the bf16 MFMA FLOPs the kernel issues "
+                                 "(6 x 2*H*H per row and panel, rows of skipped all-zero branches excluded) against the "
+                                 "dense bf16 peak; f32_equivalent_tflops = the same work counted once, shown beside the "
+                                 "dense f32 MFMA peak it would be priced at without the split.  Head: " + head_layout(pred))
             else:
                 roof = roofs[dom]
         cpu, err = None, None

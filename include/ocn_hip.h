@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define OCN_ABI_VERSION 2
+#define OCN_ABI_VERSION 3
 #define OCN_EINVAL (-1)   /* null pointer / negative size / unsupported combination */
 #define OCN_ECAP   (-2)   /* reported through the device status word: flags capacity too small */
 
@@ -99,6 +99,7 @@ int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, vo
  * here; must be zero on entry; B < 2^21.  T2 may be NULL (single adjoverlap call).
  * bitmapT2: optional dense bit rows of T2 (row j at bitmapT2 + j*bm_stride_words, bit k = column k;
  * written by ocn_spgemm_pattern_count): membership in the long A² row becomes one probe.
+ * bitmapT1: the same for T1 (ocn_bitrows_from_csr; small dense graphs); rowptrT1 / colT1 may then be NULL.
  * status: device int32, bit 0 set if off[B] > flags_cap (nothing is written past the cap).
  * order (here and below): optional permutation of 0..B-1 giving the order in which the batch rows
  * are PROCESSED (e.g. sorted by src so that rows sharing neighbourhoods meet in L2); every output
@@ -106,6 +107,7 @@ int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, vo
 int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA,
                  const int64_t* rowptrT1, const int32_t* colT1,
                  const int64_t* rowptrT2, const int32_t* colT2,
+                 const uint32_t* bitmapT1 /* or NULL */, int64_t bm1_stride_words,
                  const uint32_t* bitmapT2 /* or NULL */, int64_t bm_stride_words,
                  const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                  int64_t n_cols, const int64_t* off, uint8_t* flags, int64_t flags_cap,
@@ -302,6 +304,11 @@ int ocn_dense_from_csr(const int64_t* rowptr, const int32_t* col, int64_t n, int
                        void* stream);
 int ocn_dense_block_mm_bits(const int8_t* A, const int8_t* Bt, int64_t ld, int64_t K, int32_t r0, int32_t r1, int32_t c0,
                             int32_t c1, int32_t fold, uint32_t* bits, int64_t bm_stride_words, void* stream);
+/* Dense bit rows of a CSR pattern ([n_rows][bm_stride_words] words, ZERO on entry): what ocn_cn_flags probes as
+ * bitmapT1 on small dense graphs (ogbl-ddi: 4267 nodes, 500+ neighbours each), one load per membership test instead of a
+ * binary search of the target row. */
+int ocn_bitrows_from_csr(const int64_t* rowptr, const int32_t* col, int64_t n_rows, uint32_t* bits, int64_t bm_stride_words,
+                         void* stream);
 int ocn_bitrows_count(const uint32_t* bits, int64_t bm_stride_words, int64_t n_rows, int64_t n_cols, int32_t* row_count,
                       void* stream);
 int ocn_bitrows_fill(const uint32_t* bits, int64_t bm_stride_words, int64_t n_rows, int64_t n_cols, const int64_t* rowptr,

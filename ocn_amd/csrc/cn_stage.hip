@@ -59,7 +59,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
     const i64* __restrict__ rowptrT1, const int32_t* __restrict__ colT1,
     const i64* __restrict__ rowptrT2, const int32_t* __restrict__ colT2,
-    const unsigned* __restrict__ bmT2, i64 bm_stride,
+    const unsigned* __restrict__ bmT1, i64 bm1_stride, const unsigned* __restrict__ bmT2, i64 bm_stride,
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     i64 n_cols, const i64* __restrict__ off, uint8_t* __restrict__ flags, i64 cap,
     u64* __restrict__ hist, int32_t* __restrict__ cnt1, int32_t* __restrict__ cnt2,
@@ -80,10 +80,12 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     const i64 e = act ? (order ? order[slot] : slot) : 0;
     i64 a0 = 0, da = 0, b0 = 0, db = 0, c0 = 0, dc = 0, base = 0;
     const unsigned* bm_row = nullptr;         // bit row of dst in T2, when T2 comes with a dense bitmap
+    const unsigned* bm1_row = nullptr;        // ... and in T1 (small dense graphs: a membership test is one probe)
     if (act) {
       const i64 i = src[e], j = dst[e];
       a0 = rowptrA[i]; da = rowptrA[i + 1] - a0;
-      b0 = rowptrT1[j]; db = rowptrT1[j + 1] - b0;
+      if (bmT1) bm1_row = bmT1 + j * bm1_stride;
+      else { b0 = rowptrT1[j]; db = rowptrT1[j + 1] - b0; }
       if (HAS_T2) {
         if (bmT2) bm_row = bmT2 + j * bm_stride;
         else { c0 = rowptrT2[j]; dc = rowptrT2[j + 1] - c0; }
@@ -111,7 +113,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
 #ifdef OCN_X_NOT1   /* OCN_X_*: timing experiments of tools/kbench.py, never defined in the product build */
       const bool f1 = (k & 7) == 0;
 #else
-      const bool f1 = t1_lds ? sorted_has(&s_t1[g][0], db, k) : sorted_has(colT1 + b0, db, k);
+      const bool f1 = bmT1 ? (bool)((bm1_row[k >> 5] >> (k & 31)) & 1u)
+                           : (t1_lds ? sorted_has(&s_t1[g][0], db, k) : sorted_has(colT1 + b0, db, k));
 #endif
       bool f2 = false;
 #ifdef OCN_X_NOT2
@@ -697,9 +700,17 @@ __device__ __forceinline__ void pool_store(i64 e, i64 i, i64 j, int gl, const fl
 // groups take contiguous segments of the row and the partial sums are added in segment order.
 // Rows up to LONG_ROW keep the strictly sequential ascending-column sum of the reference's spmm.
 #define LONG_ROW 1024
+#ifndef GATHER_SLICE_MIN_BATCH
+#define GATHER_SLICE_MIN_BATCH 16384     /* candidates from which the pooling of H >= 256 runs one feature slice per XCD */
+#endif
 
 // LPE lanes cooperate on one edge (64/LPE edges per wave).
-template <int LPE, int NV>
+// SLICED: the H features are cut into 8 slices of LPE*NV*4 and workgroup b pools slice b % 8 of its candidates.
+// Workgroups are dealt round-robin over the 8 XCDs, so XCD x only ever reads feature slice x of the embedding
+// table: every row slice has ONE home L2 (a row shared by candidates on different XCDs is no longer fetched up to
+// eight times) and that L2 holds 8x as many rows.  Every feature is still summed on its own in ascending column
+// order, so the result does not change by a bit.
+template <int LPE, int NV, bool SLICED = false>
 __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
@@ -716,17 +727,24 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
   // visited in source-node order, so give every XCD one contiguous eighth of that order: rows
   // with neighbouring sources then share an L2 instead of being spread over all eight.
   i64 bid = blockIdx.x;
+  int slice = 0;
+  if (SLICED) {
+    slice = (int)(bid & 7);
+    bid >>= 3;
+  } else {
 #ifndef OCN_X_NOXCD
-  if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
 #endif
+  }
   const i64 slot = (bid * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
   if (slot >= B) return;                    // whole group leaves together
   const i64 e = order ? order[slot] : slot;
   const i64 i = src[e], j = dst[e];
   const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
   if (da > LONG_ROW) return;                // cn_gather_long_kernel's
-  const float4* h4 = reinterpret_cast<const float4*>(h);
+  const float4* h4 = reinterpret_cast<const float4*>(h) + slice * (LPE * NV);
   const i64 rowq = H >> 2;                  // float4 per row
+  if (SLICED) { xcn1 += slice * (LPE * NV * 4); xcn2 += slice * (LPE * NV * 4); xij += slice * (LPE * NV * 4); }
   float4 acc1[NV], acc2[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1149,11 +1167,29 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
       packed = false;
     }
   }
-  if (packed)
-    hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)), dim3(OCN_BLOCK), 0, st,
-                       (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B,
-                       (const i64*)off, flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij,
-                       (const i64*)out_row, cnt1, cnt2);
+#define PACKED_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, \
+                    (const i64*)off, flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij,           \
+                    (const i64*)out_row, cnt1, cnt2
+  if (packed) {
+    bool sliced = false;
+#ifdef OCN_X_SLICE
+    // EXPERIMENT, off in the product (pooling): one feature slice per XCD.  Bit-identical scores, but 8
+    // candidates share a wave and run in lockstep to the longest of them: 0.76 ms against 0.22 ms at the collab shape.
+    if constexpr (LPE * NV >= 64 && (LPE * NV) % 8 == 0) {
+      constexpr int SL = LPE * NV / 8;                           // float4 per slice
+      const i64 spb = (i64)OCN_WPB * (OCN_WAVE / SL);
+      if (B >= GATHER_SLICE_MIN_BATCH) {
+        hipLaunchKernelGGL((cn_gather_kernel<SL, 1, true>), dim3((unsigned)(8 * ((B + spb - 1) / spb))), dim3(OCN_BLOCK),
+                           0, st, PACKED_ARGS);
+        sliced = true;
+      }
+    }
+#endif
+    if (!sliced)
+      hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)), dim3(OCN_BLOCK), 0, st,
+                         PACKED_ARGS);
+  }
+#undef PACKED_ARGS
 #define LONG_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, wc, \
                   (const float4*)weights, h, (int)H, xcn1, xcn2, xij, (const i64*)out_row
   if (max_row_len > LONG_ROW) {
@@ -1167,13 +1203,14 @@ extern "C" {
 
 int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* rowptrT1,
                  const int32_t* colT1, const int64_t* rowptrT2, const int32_t* colT2,
-                 const uint32_t* bitmapT2, int64_t bm_stride_words,
+                 const uint32_t* bitmapT1, int64_t bm1_stride_words, const uint32_t* bitmapT2, int64_t bm_stride_words,
                  const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                  int64_t n_cols, const int64_t* off, uint8_t* flags, int64_t flags_cap, uint64_t* hist,
                  int32_t* cnt1, int32_t* cnt2, int32_t* status, void* stream) {
   if (B < 0 || flags_cap < 0 || B > (int64_t)HF_MASK) return OCN_EINVAL;
   if (B == 0) return 0;
-  if (!rowptrA || !rowptrT1 || !src || !dst || !off || !hist || !cnt1 || !status) return OCN_EINVAL;
+  if (!rowptrA || (!rowptrT1 && !bitmapT1) || !src || !dst || !off || !hist || !cnt1 || !status) return OCN_EINVAL;
+  if ((bitmapT1 && bm1_stride_words * 32 < n_cols) || (bitmapT2 && bm_stride_words * 32 < n_cols)) return OCN_EINVAL;
   // col pointers may legitimately be NULL for an adjacency with no entries
   constexpr int GPB = OCN_BLOCK / OCN_X_G;
   hipStream_t st = (hipStream_t)stream;
@@ -1200,7 +1237,7 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
   }
 #define CN_FLAGS_ARGS(T2P, T2C)                                                                      \
   (const i64*)rowptrA, colA, (const i64*)rowptrT1, colT1, (const i64*)(T2P), (T2C),                   \
-      (const unsigned*)bitmapT2, (i64)bm_stride_words, (const i64*)src,                                \
+      (const unsigned*)bitmapT1, (i64)bm1_stride_words, (const unsigned*)bitmapT2, (i64)bm_stride_words, (const i64*)src, \
       (const i64*)dst, (const i64*)order, (i64)B, (i64)n_cols, (const i64*)off, flags, (i64)flags_cap, \
       (u64*)hist, cnt1, cnt2, status
   if (rowptrT2) {

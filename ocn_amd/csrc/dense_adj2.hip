@@ -112,6 +112,19 @@ __global__ __launch_bounds__(OCN_BLOCK) void bitrows_kernel(const unsigned* __re
   }
 }
 
+// A CSR pattern as dense bit rows (bits ZERO on entry): one wave per row, a lane sets the bits of its entries.
+__global__ __launch_bounds__(OCN_BLOCK) void csr_bitrows_kernel(const i64* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                i64 n_rows, unsigned* __restrict__ bits, i64 bm_stride) {
+  const int lane = threadIdx.x & 63;
+  for (i64 r = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6); r < n_rows; r += (i64)gridDim.x * OCN_WPB) {
+    const i64 a = rowptr[r], b = rowptr[r + 1];
+    for (i64 p = a + lane; p < b; p += OCN_WAVE) {
+      const int32_t c = col[p];
+      atomicOr(bits + r * bm_stride + (c >> 5), 1u << (c & 31));
+    }
+  }
+}
+
 extern "C" {
 
 int ocn_dense_from_csr(const int64_t* rowptr, const int32_t* col, int64_t n, int64_t ld, int8_t* dense, int8_t* denseT,
@@ -135,6 +148,16 @@ int ocn_dense_block_mm_bits(const int8_t* A, const int8_t* Bt, int64_t ld, int64
   hipLaunchKernelGGL(dense_block_mm_kernel, dim3(tiles), dim3(OCN_BLOCK), 0, (hipStream_t)stream, A, Bt, (i64)ld, kpad,
                      (int)r0, (int)r1, (int)c0, (int)c1, fold ? (int)r0 : 0, fold ? (int)c0 : 0, (unsigned*)bits,
                      (i64)bm_stride_words);
+  return launch_status();
+}
+
+int ocn_bitrows_from_csr(const int64_t* rowptr, const int32_t* col, int64_t n_rows, uint32_t* bits, int64_t bm_stride_words,
+                         void* stream) {
+  if (n_rows < 0 || bm_stride_words < 0) return OCN_EINVAL;
+  if (n_rows == 0) return 0;
+  if (!rowptr || !bits) return OCN_EINVAL;
+  hipLaunchKernelGGL(csr_bitrows_kernel, dim3(grid_for((n_rows + OCN_WPB - 1) / OCN_WPB, 1 << 16)), dim3(OCN_BLOCK), 0,
+                     (hipStream_t)stream, (const i64*)rowptr, col, (i64)n_rows, (unsigned*)bits, (i64)bm_stride_words);
   return launch_status();
 }
 

@@ -30,6 +30,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define HD_ROWS 128
 #define HD_KC 2                       /* k-steps per staged panel chunk */
+#ifndef HD_VMEM_SLOTS
+#define HD_VMEM_SLOTS 20                  /* MFMA gaps of a k-step that may carry an LDS-DMA piece */
+#endif
 #define HD_NVEC 17                    /* epilogue vectors of H floats, then one scalar (dot bias) */
 enum { V_B0A = 0, V_B3A, V_G3A, V_E3A, V_B0B, V_B3B, V_G3B, V_E3B, V_B0X, V_GX, V_EX, V_BF, V_GL, V_EL, V_DOTW, V_CA, V_CB };
 
@@ -121,7 +124,9 @@ struct Heads {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
         if (m < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // one fragment read of the next tile
         __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);           // VALU
-        if (m % 3 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // an LDS-DMA piece
+        // the LDS-DMA pieces of the next chunk: one behind each of the FIRST MFMAs of the k-step, so that they have the
+        // rest of this k-step and all of the next to land before the chunk boundary waits for them
+        if (t * 6 + m < HD_VMEM_SLOTS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);           // SALU (M0, addresses)
       }
     __builtin_amdgcn_sched_barrier(0);
@@ -229,6 +234,9 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
   // where this wave parks a finished branch's share of the output while the next branch needs the registers
   float4* park = reinterpret_cast<float4*>(a.scratch) + ((size_t)(blockIdx.x * 4 + w) * 2) * (NT * 4) * 64 + lane;
   const i64 n_tiles = a.dump ? 1 : (a.B + HD_ROWS - 1) / HD_ROWS;
+#ifdef OCN_X_HD_CLOCK                /* diagnostic build only: the clock the chip holds under this kernel (guide, DVFS give-back item 6) */
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
 #pragma unroll 1
   for (i64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -447,6 +455,13 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
     d += __shfl_xor(d, 32, OCN_WAVE);
     if (live && hh == 0 && !a.dump) a.y[a.y_row_map ? a.y_row_map[slot] : slot] = d + s_vec[HD_NVEC * H];
   }
+#ifdef OCN_X_HD_CLOCK
+  if (threadIdx.x == 0) {            // into this workgroup's own (now dead) park area: nothing reads it
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(reinterpret_cast<float4*>(a.scratch) + ((size_t)(blockIdx.x * 4) * 2) * (NT * 4) * 64);
+    o[0] = __builtin_amdgcn_s_memtime() - clk0;
+    o[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
+#endif
 }
 
 // Wp[s][t][split][lane][8] of a CHAINED layer: k-step s = 2 tt + ss consumes accumulator tile tt, registers

@@ -18,6 +18,7 @@ FLAGS_NOSYNC_LIMIT = 1 << 30     # bytes of flag buffer we are willing to over-a
 validate_indices = True          # bounds-check candidate edges on the host side (one sync per batch)
 stage_timer = None               # optional object with .mark(name): bench.py records HIP events between stages
 LN_WIDTHS = (16, 32, 64, 128, 256, 512)   # row widths of the lane-group kernels (LayerNorm, pooling backward)
+a1_bitmap_max_bytes = 64 << 20   # keep A itself as dense bit rows too when they fit this (ogbl-ddi: 2.3 MB): cn1 membership = one probe
 a2_bitmap_max_bytes = 16 << 30   # keep A·B also as dense bit rows when n_rows * n_cols / 8 fits this budget
 skip_zero_rows = True            # heads: skip the layers whose pooled input row is all zero (class-major rows)
 skip_zero_min_share = 0.15       # ... and when fewer than this share of the head rows could be skipped (probed asynchronously)
@@ -176,7 +177,8 @@ def hist_counts(hist: Tensor) -> Tensor:
 @_on_device
 def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
              t2: Optional[Tuple[Tensor, Tensor]], src: Tensor, dst: Tensor, n_cols: int, max_deg_a: int,
-             walk: bool = False, t2_bitmap: Optional[Tensor] = None, wsd=None, nds: Optional[Tensor] = None):
+             walk: bool = False, t2_bitmap: Optional[Tensor] = None, wsd=None, nds: Optional[Tensor] = None,
+             t1_bitmap: Optional[Tensor] = None):
     """Intersection pass.  ``walk=False``: flags of N(src) against the rows of dst in t1 (and t2).
     ``walk=True``: the pygho route on A itself (t1/t2 ignored): cn1 flags + walk counts; with ``nds``
     (``neighbor_degree_sum`` of A) every batch row is swept from its cheaper endpoint.
@@ -244,8 +246,13 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
             _req(t2_bitmap, torch.int32, "t2_bitmap", 2)
             if t2 is None or t2_bitmap.shape[0] != t2[0].numel() - 1 or t2_bitmap.shape[1] * 32 < n_cols:
                 raise ValueError("t2_bitmap does not match the T2 adjacency")
+        if t1_bitmap is not None:
+            _req(t1_bitmap, torch.int32, "t1_bitmap", 2)
+            if t1_bitmap.shape[0] != t1[0].numel() - 1 or t1_bitmap.shape[1] * 32 < n_cols:
+                raise ValueError("t1_bitmap does not match the T1 adjacency")
         check(_lib.lib().ocn_cn_flags(ptr(rowptrA), ptr(colA), ptr(t1[0]), ptr(t1[1]),
                                       ptr(t2[0] if t2 else None), ptr(t2[1] if t2 else None),
+                                      ptr(t1_bitmap), t1_bitmap.shape[1] if t1_bitmap is not None else 0,
                                       ptr(t2_bitmap), t2_bitmap.shape[1] if t2_bitmap is not None else 0,
                                       ptr(src), ptr(dst), ptr(order), B, n_cols, ptr(off), ptr(flags), cap, ptr(hist),
                                       ptr(cnt1), ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_flags")
@@ -514,6 +521,16 @@ def deg_rsqrt(rowptr: Tensor, add: float = 1.0, val: Optional[Tensor] = None) ->
     out = torch.empty(n, dtype=torch.float32, device=rowptr.device)
     check(_lib.lib().ocn_deg_rsqrt(ptr(rowptr), ptr(val), n, float(add), ptr(out), stream_ptr()), "ocn_deg_rsqrt")
     return out
+
+
+@_on_device
+def bitrows_from_csr(rowptr: Tensor, col: Tensor, n_cols: int) -> Tensor:
+    """ocn_hip.h: ocn_bitrows_from_csr — the pattern as dense bit rows, int32 [n_rows, ceil(n_cols / 32)]."""
+    _req(rowptr, torch.int64, "rowptr", 1); _req(col, torch.int32, "col", 1)
+    n = rowptr.numel() - 1
+    bits = torch.zeros(n, (int(n_cols) + 31) // 32, dtype=torch.int32, device=rowptr.device)
+    check(_lib.lib().ocn_bitrows_from_csr(ptr(rowptr), ptr(col), n, ptr(bits), bits.shape[1], stream_ptr()), "ocn_bitrows_from_csr")
+    return bits
 
 
 @_on_device

@@ -151,6 +151,16 @@ class SparseTensor:
             self._maxdeg = int((self._rowptr[1:] - self._rowptr[:-1]).max()) if self._sizes[0] else 0
         return self._maxdeg
 
+    def bit_rows(self) -> Optional[Tensor]:
+        """The pattern as dense bit rows (cached, built once by ocn_bitrows_from_csr) when they fit
+        ``ops.a1_bitmap_max_bytes``, else None: what the intersection kernel probes instead of searching a row
+        (a product of ``matmul`` arrives with its bit rows already)."""
+        if self._bitmap is None and self._rowptr.is_cuda:
+            n, m = self._sizes
+            if 0 < n * ((m + 31) // 32) * 4 <= ops.a1_bitmap_max_bytes:
+                self._bitmap = ops.bitrows_from_csr(self._rowptr, self._col, m)
+        return self._bitmap
+
     def neighbor_degree_sum(self) -> Tensor:
         """Σ_{u∈N(v)} deg(u) per node, cached: lets the walk-count route sweep each candidate edge from
         its cheaper endpoint (ocn_hip.h: ocn_neighbor_degree_sum).  Square adjacencies only."""

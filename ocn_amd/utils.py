@@ -68,7 +68,8 @@ class CNState:
             adj._rowptr, adj._col, None if walk else (t1._rowptr, t1._col),
             None if (walk or t2 is None) else (t2._rowptr, t2._col), self.src, self.dst, self.N,
             adj.max_rowcount(), walk=walk, t2_bitmap=None if (walk or t2 is None) else t2._bitmap, wsd=ws,
-            nds=adj.neighbor_degree_sum() if (walk and ops.walk_two_sided) else None)
+            nds=adj.neighbor_degree_sum() if (walk and ops.walk_two_sided) else None,
+            t1_bitmap=None if walk else t1.bit_rows())
         self._hist_live = True
 
     @classmethod

@@ -871,6 +871,32 @@ def test_bitmap_and_csr_search_of_adj2_agree(case):
     assert torch.equal(pop, case.adj2.storage.rowcount())
 
 
+def test_bitmap_and_csr_search_of_adj_agree(case, monkeypatch):
+    """cn1 membership: A itself is probed through dense bit rows when they fit ``ops.a1_bitmap_max_bytes`` (every small
+    graph, ogbl-ddi), otherwise the target row is searched (LDS copy + binary search: collab and larger).  Both give
+    the oracle's flags; the bit rows are the CSR pattern."""
+    from ocn_amd import ops
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import CNState
+    e = case.e.to(DEV)
+    with_bits = SparseTensor(rowptr=case.adj._rowptr, col=case.adj._col, sparse_sizes=case.adj.sparse_sizes())
+    bits = with_bits.bit_rows()
+    assert bits is not None and bits.shape == (case.n, (case.n + 31) // 32)
+    dense = torch.zeros(case.n, bits.shape[1] * 32, dtype=torch.bool, device=DEV)
+    r, c, _ = case.adj.coo()
+    dense[r, c] = True
+    got = ((bits.view(torch.uint8).unsqueeze(-1) >> torch.arange(8, device=DEV, dtype=torch.uint8)) & 1).bool().reshape(case.n, -1)
+    assert torch.equal(got, dense)
+    a = CNState(case.adj, with_bits, case.adj2, e)
+    monkeypatch.setattr(ops, "a1_bitmap_max_bytes", 0)
+    searched = SparseTensor(rowptr=case.adj._rowptr, col=case.adj._col, sparse_sizes=case.adj.sparse_sizes())
+    assert searched.bit_rows() is None
+    b = CNState(case.adj, searched, case.adj2, e)
+    assert torch.equal(a.cnt1, b.cnt1) and torch.equal(a.cnt2, b.cnt2) and torch.equal(a.hist, b.hist)
+    assert torch.equal(a.flags[: int(a.off[-1])], b.flags[: int(b.off[-1])])
+    assert b.cnt1.cpu().tolist() == torch.bincount(case.ocn1.row, minlength=case.B).tolist()
+
+
 def test_eval_caches_follow_parameter_updates(case):
     """The eval fast path caches weight panels and mix coefficients; optimiser-style in-place updates
     (version bump) and .data edits followed by a mode switch must both be seen."""

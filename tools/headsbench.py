@@ -27,10 +27,16 @@ for H, B in ((256, 65536), (64, 32768)):
             pred._heads_fused(x1, x2, xij, None)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = 20
+        n = int(os.environ.get("HB_N", 20))
         for _ in range(n):
             pred._heads_fused(x1, x2, xij, None)
         torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
     fl = 2.0 * H * H * 8 * B
+    if "-DOCN_X_HD_CLOCK" in flags:        # in-kernel clock: d(s_memtime) / d(s_memrealtime) x 100 MHz, median over workgroups
+        sc = [v for v in pred._ws.values() if torch.is_tensor(v) and v.numel() * 4 == int(_lib.lib().ocn_heads_scratch_bytes(H))][0]
+        per = 4 * 2 * (H // 32) * 4 * 64 * 16 // 8           # u64 words of one workgroup's park area
+        st = sc.view(torch.int64).view(-1, per)[:, :2].double()
+        ghz = (st[:, 0] / st[:, 1] * 0.1).median().item()
+        print(f"in-kernel clock {ghz:.2f} GHz; kernel cycles (median WG) {st[:, 0].median().item():.0f}", flush=True)
     print(f"{' '.join(flags) or 'product':28s} H={H} B={B}: {dt * 1e6:8.1f} us  {fl / dt / 1e12:6.1f} TF f32-equivalent  {6 * fl / dt / 1e15:5.2f} PF bf16 issued", flush=True)

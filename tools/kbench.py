@@ -25,10 +25,10 @@ def child():
     from ocn_amd.utils import CNState
     args = argparse.Namespace(dataset=os.environ.get("KB_DATASET", "collab"), scale=1.0,
                               hiddim=int(os.environ.get("KB_H", "256")), predictor="cn5",
-                              batch=int(os.environ.get("KB_B", "65536")))
+                              batch=int(os.environ.get("KB_B", "65536")), batches=1, innerprod=0.0)
     dev = torch.device("cuda:0")
     wl = bench.build_workload(args, dev, 0, 1)
-    adj, adj2, h, e = wl["adj"], wl["adj2"], wl["h"], wl["edges"]
+    adj, adj2, h, e = wl["adj"], wl["adj2"], wl["h"], wl["edges"][0]
     ops.validate_indices = False
     iters = int(os.environ.get("KB_ITERS", "20"))
     mode = os.environ.get("KB_SORT", "")
