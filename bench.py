@@ -473,7 +473,7 @@ def main():
                 launches_per_step = stages["linear"]["launches"] / sampled
                 Bm = mines[0].shape[1]
                 t = stages["linear"]["ms"] * 1e-3
-                fused = bool(ops.fused_heads and getattr(pred, "_fused_plan", lambda H: None)(H) is not None)
+                fused = bool(ops.fused_heads and H >= ops.fused_heads_min_width and getattr(pred, "_fused_plan", lambda H: None)(H) is not None)
                 ref_fl = timer.flops.get("linear", 0.0) / stages["linear"]["launches"]
                 skip = getattr(pred, "_skip_state", None)
                 skipping = bool(ops.skip_zero_rows and skip is not None and skip["off"] == 0 and Bm >= ops.skip_zero_min_batch)

@@ -615,6 +615,12 @@ __device__ __forceinline__ void pool_range(i64 p_begin, i64 p_end, i64 a0, i64 b
   // per LPE positions: a lane fetches PT positions per round, so a round always covers 64 of them
   // (hub rows of the ppa shape: 101 -> 40 us).
   constexpr int PT = (OCN_WAVE / LPE) < 8 ? (OCN_WAVE / LPE) : 8;
+  f32x2 acc[NV][4];                          // {acc1, acc2} component pairs: one packed multiply + add per pair
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    acc[v][0] = f32x2{acc1[v].x, acc2[v].x}; acc[v][1] = f32x2{acc1[v].y, acc2[v].y};
+    acc[v][2] = f32x2{acc1[v].z, acc2[v].z}; acc[v][3] = f32x2{acc1[v].w, acc2[v].w};
+  }
   for (i64 p0 = p_begin; p0 < p_end; p0 += LPE * PT) {
     int32_t k[PT];
     unsigned f[PT];
@@ -664,15 +670,23 @@ __device__ __forceinline__ void pool_range(i64 p_begin, i64 p_end, i64 a0, i64 b
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           if (bsel[u] >= 0) {
+            const f32x2 w = {wwa[u], wwb[u]};
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-              axpy4(acc1[v], wwa[u], x[u][v]);
-              axpy4(acc2[v], wwb[u], x[u][v]);
+              axpy_pair(acc[v][0], w, x[u][v].x);
+              axpy_pair(acc[v][1], w, x[u][v].y);
+              axpy_pair(acc[v][2], w, x[u][v].z);
+              axpy_pair(acc[v][3], w, x[u][v].w);
             }
           }
         }
       }
     }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    acc1[v] = make_float4(acc[v][0].x, acc[v][1].x, acc[v][2].x, acc[v][3].x);
+    acc2[v] = make_float4(acc[v][0].y, acc[v][1].y, acc[v][2].y, acc[v][3].y);
   }
 }
 
@@ -756,42 +770,94 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
                       !out_row || has1, !out_row || has1 || has2);
 }
 
+// The sequential sum of ranks [0, nr) of a compacted round: acc += w[r] * x[r], one multiply and one add per entry and
+// accumulator, in rank order.  Eight entries' operands are read from LDS ahead of their adds — a rolled loop would pay
+// the LDS latency once per entry (the hub rows of the citation2 shape: 0.45 ms -> see DESIGN.md).
+template <int FPL, int HF>
+__device__ __forceinline__ void chain_rows(const float2* __restrict__ w, const float* __restrict__ xs, int nr,
+                                           float (&acc1)[FPL], float (&acc2)[FPL]) {
+  constexpr int BLK = FPL >= 4 ? 2 : 8 / FPL;       // entries per block: 2 * BLK * FPL operand registers per lane
+  f32x2 acc[FPL];
+#pragma unroll
+  for (int q = 0; q < FPL; ++q) acc[q] = f32x2{acc1[q], acc2[q]};
+  auto load = [&](int r, float2 (&w8)[BLK], float (&x8)[BLK][FPL]) {
+#pragma unroll
+    for (int u = 0; u < BLK; ++u) {
+      w8[u] = w[r + u];
+#pragma unroll
+      for (int q = 0; q < FPL; ++q) x8[u][q] = xs[(r + u) * HF + q];
+    }
+  };
+  auto add = [&](const float2 (&w8)[BLK], const float (&x8)[BLK][FPL]) {
+#pragma unroll
+    for (int u = 0; u < BLK; ++u)
+#pragma unroll
+      for (int q = 0; q < FPL; ++q) axpy_pair(acc[q], f32x2{w8[u].x, w8[u].y}, x8[u][q]);
+  };
+  const int nb = nr / BLK;                   // blocks of BLK entries, two register sets: block b + 1 is read while b is added
+  if (nb > 0) {
+    float2 wa[BLK], wb[BLK];
+    float xa[BLK][FPL], xb[BLK][FPL];
+    load(0, wa, xa);
+    int b = 0;
+    for (; b + 2 <= nb; b += 2) {
+      load((b + 1) * BLK, wb, xb);
+      add(wa, xa);
+      if (b + 2 < nb) load((b + 2) * BLK, wa, xa);
+      add(wb, xb);
+    }
+    if (b < nb) add(wa, xa);
+  }
+  for (int r = nb * BLK; r < nr; ++r) {
+    const float2 wr = w[r];
+#pragma unroll
+    for (int q = 0; q < FPL; ++q) axpy_pair(acc[q], f32x2{wr.x, wr.y}, xs[r * HF + q]);
+  }
+#pragma unroll
+  for (int q = 0; q < FPL; ++q) { acc1[q] = acc[q].x; acc2[q] = acc[q].y; }
+}
+
 // Small batches of narrow embeddings (ppa / citation2: B = 2048, H = 32..64) leave the packed kernel
 // above with a few hundred waves, each lane group walking its row 4 gathers at a time.  Here ONE WAVE
 // takes one batch row: per round of 64 positions the live entries are compacted (rank = position among
 // the live ones), the 64/LPE lane groups fetch all their embedding rows at once (up to 64 gathers in
 // flight per wave) into the wave's LDS slab, and lane group 0 accumulates them in rank order — the
 // same sequential ascending-column fp32 sum as the packed kernel, bit for bit.
-template <int LPE, int NV>
-__global__ __launch_bounds__(OCN_BLOCK) void cn_gather_wave_kernel(
+// LONG: the same kernel over the batch rows whose source row is LONGER than LONG_ROW only (large batches of narrow
+// embeddings on a dense graph — ogbl-ddi: a third of the candidates have such a source; a lane group of the packed
+// kernel would walk 2 000 positions four gathers at a time).
+template <int LPE, int NV, bool LONG = false, int WPB = (LONG ? 1 : OCN_WPB)>
+__global__ __launch_bounds__(WPB * OCN_WAVE) void cn_gather_wave_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
     float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij,
     const i64* __restrict__ out_row) {   // out_row[batch row] = output row (class-major heads), or NULL
+  // WPB waves per workgroup: ONE for the LONG pass — most batch rows are not its and leave at once, and a wave that
+  // has left frees its LDS slab only when it is a workgroup of its own.
   constexpr int G = OCN_WAVE / LPE;
   constexpr int UNR = LPE;                  // G * UNR = 64 rows: a whole round in flight
-  __shared__ float4 s_x[OCN_WPB][OCN_WAVE][LPE * NV];
-  __shared__ int32_t s_k[OCN_WPB][OCN_WAVE];
-  __shared__ float2 s_w[OCN_WPB][OCN_WAVE];
+  constexpr int HF = LPE * NV * 4;          // features: lane l < HF accumulates feature l (all lanes busy at H = 64,
+  static_assert(HF <= OCN_WAVE, "");        // a quarter of the VALU work per entry of a float4-per-lane layout)
+  __shared__ float4 s_x[WPB][OCN_WAVE][LPE * NV];
+  __shared__ int32_t s_k[WPB][2][OCN_WAVE];
+  __shared__ float2 s_w[WPB][2][OCN_WAVE];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int gl = lane % LPE, g = lane / LPE;
-  const i64 slot = (i64)blockIdx.x * OCN_WPB + wv;
+  const i64 slot = (i64)blockIdx.x * WPB + wv;
   if (slot >= B) return;                    // whole wave leaves together (no workgroup barriers below)
   const i64 e = order ? order[slot] : slot;
   const i64 i = src[e], j = dst[e];
   const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
-  if (da > LONG_ROW) return;                // cn_gather_long_kernel's
+  if (LONG ? da <= LONG_ROW : da > LONG_ROW) return;       // the other launch's rows
   const i64 base = off[e];
   const float4* h4 = reinterpret_cast<const float4*>(h);
   const i64 rowq = H >> 2;
-  float4 acc1[NV], acc2[NV];
-#pragma unroll
-  for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // Software pipeline over the 64-position rounds: a round needs column id -> column weights -> rows,
-  // three dependent trips to memory; the ids of round r+2 and the weights of round r+1 are requested
-  // before round r's rows are gathered.
+  float acc1[1] = {0.f}, acc2[1] = {0.f};
+  // Software pipeline over the 64-position rounds: a round needs column id -> column weights -> rows, three dependent
+  // trips to memory, then the sequential sum.  The ids of round r+2 and the weights of round r+1 are requested before
+  // round r's rows are; round r+1 is compacted and its rows requested (into registers) before round r is summed.
   int32_t k_n = 0, k_nn = 0, cv_n = 1, cv_nn = 1;
   unsigned f_n = 0, f_nn = 0;
   if (lane < da) { k_n = colA[a0 + lane]; f_n = flags[base + lane]; if (wc) cv_n = wc[base + lane]; }
@@ -801,7 +867,10 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_wave_kernel(
   }
   float4 w_n = make_float4(0.f, 0.f, 0.f, 0.f);
   if (f_n) w_n = weights[k_n];
-  for (i64 p0 = 0; p0 < da; p0 += OCN_WAVE) {
+  f32x4 x[UNR][NV];
+  // compact the round at positions [p0, p0 + 64) into half `b` of s_k / s_w (rank = position among the live entries),
+  // advance the id / weight prefetch, request the round's rows; returns its number of live entries
+  auto stage = [&](i64 p0, int b) -> int {
     const int32_t k = k_n, cv = cv_n;
     const unsigned f = f_n;
     const float4 wk = w_n;
@@ -818,54 +887,91 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_wave_kernel(
     const bool need = (wa != 0.f) | (wb != 0.f);
     const unsigned long long m = __ballot(need);
     const int n = __popcll(m);
-    if (n == 0) continue;
-    if (need) {                              // compaction by rank
+    if (need) {
       const int rank = __popcll(m & ((1ull << lane) - 1ull));
-      s_k[wv][rank] = k;
-      s_w[wv][rank] = make_float2(wa, wb);
+      s_k[wv][b][rank] = k;
+      s_w[wv][b][rank] = make_float2(wa, wb);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    float4 x[UNR][NV];
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
-      const int r = u * G + g;
-      const float4* row = h4 + (i64)s_k[wv][r < n ? r : 0] * rowq + gl;
+    for (int u = 0; u < UNR; ++u) {          // unconditional loads (a predicated one is followed by a wait for it): ranks past
+      const int r = u * G + g;               // the last live entry read row 0 and are never stored
+      const int32_t kr = r < n ? s_k[wv][b][r] : 0;
+      const f32x4* row = reinterpret_cast<const f32x4*>(h4 + (i64)kr * rowq + gl);
 #pragma unroll
-      for (int v = 0; v < NV; ++v) x[u][v] = r < n ? row[v * LPE] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int v = 0; v < NV; ++v) x[u][v] = row[v * LPE];
     }
+    return n;
+  };
+  int n = stage(0, 0);
+  int b = 0;
+  for (i64 p0 = 0; p0 < da; p0 += OCN_WAVE, b ^= 1) {
 #pragma unroll
-    for (int u = 0; u < UNR; ++u) {
+    for (int u = 0; u < UNR; ++u) {          // the rows requested a round ago -> this wave's slab
       const int r = u * G + g;
       if (r < n) {
 #pragma unroll
-        for (int v = 0; v < NV; ++v) s_x[wv][r][gl + v * LPE] = x[u][v];
+        for (int v = 0; v < NV; ++v) *reinterpret_cast<f32x4*>(&s_x[wv][r][gl + v * LPE]) = x[u][v];
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (g == 0) {
-      for (int r = 0; r < n; ++r) {
-        const float2 wr = s_w[wv][r];
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-          const float4 xs = s_x[wv][r][gl + v * LPE];
-          axpy4(acc1[v], wr.x, xs);
-          axpy4(acc2[v], wr.y, xs);
-        }
-      }
-    }
+    const int n_next = p0 + OCN_WAVE < da ? stage(p0 + OCN_WAVE, b ^ 1) : 0;
+    if (lane < HF)                           // rank order = ascending column, one feature per lane
+      chain_rows<1, HF>(&s_w[wv][b][0], reinterpret_cast<const float*>(&s_x[wv][0][0]) + lane, n, acc1, acc2);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    n = n_next;
   }
-  if (g == 0) pool_store<LPE, NV>(out_row ? out_row[e] : e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
+  if (lane < HF) {
+    const i64 o = (out_row ? out_row[e] : e) * H + lane;
+    xcn1[o] = acc1[0];
+    xcn2[o] = acc2[0];
+    xij[o] = __fmul_rn(h[i * H + lane], h[j * H + lane]);
+  }
+}
+
+// cn_gather_long_kernel's fetching lane groups: request the rows of sub-round u into registers / store them into a slab
+// half.  The loads are unconditional (a predicated load is followed by a wait for it): slots past the sub-round's rows
+// read row 0 and are never stored.
+template <int LPE, int NV, int RPG, int FG, int SLAB>
+__device__ __forceinline__ void long_request(f32x4 (&x)[RPG][NV], const int32_t* __restrict__ s_k, int u, int n, int fg,
+                                             int gl, const float4* __restrict__ h4, i64 rowq) {
+  const int r0 = u * SLAB;
+  const int nr = n - r0;                                        // <= 0 past the last sub-round
+#pragma unroll
+  for (int q = 0; q < RPG; ++q) {
+    const int r = fg + q * FG;
+    const bool ok = r < SLAB && r < nr;
+    const int32_t kr = s_k[ok ? r0 + r : 0];
+    const f32x4* row = reinterpret_cast<const f32x4*>(h4 + (i64)(ok ? kr : 0) * rowq + gl);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) x[q][v] = row[v * LPE];
+  }
+}
+
+template <int LPE, int NV, int RPG, int FG, int SLAB>
+__device__ __forceinline__ void long_store(const f32x4 (&x)[RPG][NV], float4* __restrict__ half, int nr, int fg, int gl) {
+#pragma unroll
+  for (int q = 0; q < RPG; ++q) {
+    const int r = fg + q * FG;
+    if (r < SLAB && r < nr) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) *reinterpret_cast<f32x4*>(half + r * (LPE * NV) + gl + v * LPE) = x[q][v];
+    }
+  }
 }
 
 // One workgroup per batch row whose source row is longer than LONG_ROW (hub sources; 8 403 neighbours at the citation2
 // shape).  The sum stays the reference's: strictly sequential in ascending column order.  What a workgroup adds is
-// the memory parallelism: per round of LONG_THREADS positions the live entries are compacted by rank, ALL lane groups
-// fetch their embedding rows into an LDS slab (LONG_SLAB_BYTES per sub-round), and lane group 0 alone accumulates
-// them in rank order — bit for bit the sum cn_gather_kernel forms for a short row.
+// the memory parallelism: per round of LONG_THREADS positions the live entries are compacted by rank; waves 1.. fetch
+// their embedding rows into one half of a double-buffered LDS slab while wave 0 accumulates the other half in rank
+// order — bit for bit the sum cn_gather_kernel forms for a short row.  The fetch is itself pipelined: a step writes
+// the rows requested two steps earlier into the slab and requests a later sub-round's into the registers they
+// leave, so a barrier never waits for a load issued in its own step.  Wave 0 holds the H features spread over its
+// lanes (one per lane at H <= 64, H/64 from there): the sequential chain costs a multiply and an add per lane and
+// entry and accumulator, not a float4's worth of them on a quarter of the lanes.
 // LONG_THREADS: 1024 for small batches (few hub rows, each as parallel as a workgroup gets), 256 for large ones (one
 // workgroup is launched per batch row and all but the hub rows' leave at once).
-#define LONG_SLAB_BYTES 32768
+#define LONG_SLAB_BYTES(threads) ((threads) >= 1024 ? 32768 : 16384)   /* per half; dynamic LDS = two halves */
 template <int LPE, int NV, int LONG_THREADS>
 __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
@@ -874,11 +980,16 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
     float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij,
     const i64* __restrict__ out_row) {   // out_row[batch row] = output row (class-major heads), or NULL
-  constexpr int NG = LONG_THREADS / LPE;                       // lane groups per workgroup
+  constexpr int FG = (LONG_THREADS - OCN_WAVE) / LPE;          // fetching lane groups (waves 1..)
   constexpr int ROWQ = LPE * NV;                               // float4 per embedding row
-  constexpr int SLAB = LONG_SLAB_BYTES / (16 * ROWQ);          // rows per sub-round
+  constexpr int HF = ROWQ * 4;                                 // features
+  constexpr int FPL = HF >= OCN_WAVE ? HF / OCN_WAVE : 1;      // features per lane of wave 0
+  constexpr int AL = HF / FPL;                                 // its active lanes
+  constexpr int SLAB = LONG_SLAB_BYTES(LONG_THREADS) / (16 * ROWQ);   // rows per sub-round
+  constexpr int RPG = (SLAB + FG - 1) / FG;                    // rows a fetching lane group requests per sub-round
   constexpr int WAVES = LONG_THREADS / OCN_WAVE;
-  __shared__ float4 s_x[SLAB][ROWQ];
+  static_assert(FG >= 1 && SLAB >= 1, "");
+  extern __shared__ __attribute__((aligned(16))) float4 s_x[];          // [2][SLAB][ROWQ]
   __shared__ int32_t s_k[LONG_THREADS];
   __shared__ float2 s_w[LONG_THREADS];
   __shared__ int s_wcnt[WAVES];
@@ -887,13 +998,13 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
   const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
   if (da <= LONG_ROW) return;               // whole workgroup leaves together
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int gl = threadIdx.x % LPE, g = threadIdx.x / LPE;
+  const int gl = threadIdx.x % LPE, fg = ((int)threadIdx.x - OCN_WAVE) / LPE;
   const i64 base = off[e];
   const float4* h4 = reinterpret_cast<const float4*>(h);
   const i64 rowq = H >> 2;
-  float4 acc1[NV], acc2[NV];
+  float acc1[FPL], acc2[FPL];
 #pragma unroll
-  for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int q = 0; q < FPL; ++q) acc1[q] = acc2[q] = 0.f;
   for (i64 p0 = 0; p0 < da; p0 += LONG_THREADS) {
     const i64 p = p0 + threadIdx.x;
     int32_t k = 0, cv = 1;
@@ -918,29 +1029,48 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
       s_w[rank] = make_float2(wa, wb);
     }
     __syncthreads();
-    for (int r0 = 0; r0 < n; r0 += SLAB) {
-      const int nr = n - r0 < SLAB ? n - r0 : SLAB;
-      for (int r = g; r < nr; r += NG) {
-        const float4* row = h4 + (i64)s_k[r0 + r] * rowq + gl;
-#pragma unroll
-        for (int v = 0; v < NV; ++v) s_x[r][gl + v * LPE] = row[v * LPE];
+    const int nsr = (n + SLAB - 1) / SLAB;
+    // Sub-round u lives in register set u & 1 of the fetching waves from its request until it is stored two steps
+    // later.  Step t: waves 1.. store sub-round t + 1 and request t + 3 into the set it leaves; wave 0 sums sub-round t
+    // from the slab half t & 1; barrier.
+    f32x4 xa[RPG][NV], xb[RPG][NV];
+    if (wv > 0) {
+      long_request<LPE, NV, RPG, FG, SLAB>(xa, s_k, 0, n, fg, gl, h4, rowq);
+      long_request<LPE, NV, RPG, FG, SLAB>(xb, s_k, 1, n, fg, gl, h4, rowq);
+    }
+    for (int t = -1; t < nsr; t += 2) {
+      // t + 1 is even: set a
+      if (wv > 0) {
+        long_store<LPE, NV, RPG, FG, SLAB>(xa, s_x + (size_t)((t + 1) & 1) * SLAB * ROWQ, n - (t + 1) * SLAB, fg, gl);
+        long_request<LPE, NV, RPG, FG, SLAB>(xa, s_k, t + 3, n, fg, gl, h4, rowq);
+      } else if (t >= 0 && lane < AL) {
+        const int r0 = t * SLAB;
+        chain_rows<FPL, HF>(s_w + r0, reinterpret_cast<const float*>(s_x + (size_t)(t & 1) * SLAB * ROWQ) + lane * FPL,
+                            n - r0 < SLAB ? n - r0 : SLAB, acc1, acc2);
       }
       __syncthreads();
-      if (g == 0) {
-        for (int r = 0; r < nr; ++r) {
-          const float2 wr = s_w[r0 + r];
-#pragma unroll
-          for (int v = 0; v < NV; ++v) {
-            const float4 xs = s_x[r][gl + v * LPE];
-            axpy4(acc1[v], wr.x, xs);
-            axpy4(acc2[v], wr.y, xs);
-          }
+      if (t + 1 < nsr) {                                        // uniform: every thread takes the same barriers
+        if (wv > 0) {
+          long_store<LPE, NV, RPG, FG, SLAB>(xb, s_x + (size_t)((t + 2) & 1) * SLAB * ROWQ, n - (t + 2) * SLAB, fg, gl);
+          long_request<LPE, NV, RPG, FG, SLAB>(xb, s_k, t + 4, n, fg, gl, h4, rowq);
+        } else if (lane < AL) {
+          const int r0 = (t + 1) * SLAB;
+          chain_rows<FPL, HF>(s_w + r0, reinterpret_cast<const float*>(s_x + (size_t)((t + 1) & 1) * SLAB * ROWQ) + lane * FPL,
+                              n - r0 < SLAB ? n - r0 : SLAB, acc1, acc2);
         }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
-  if (g == 0) pool_store<LPE, NV>(out_row ? out_row[e] : e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij);
+  if (wv == 0 && lane < AL) {
+    const i64 o = (out_row ? out_row[e] : e) * H + lane * FPL;
+#pragma unroll
+    for (int q = 0; q < FPL; ++q) {
+      xcn1[o + q] = acc1[q];
+      xcn2[o + q] = acc2[q];
+      xij[o + q] = __fmul_rn(h[i * H + lane * FPL + q], h[j * H + lane * FPL + q]);
+    }
+  }
 }
 
 // cn6 pooling: three pooled vectors.  flagsA carries the cn1 / cn2 bits, flagsB's bit 0 the cn3 bit (two
@@ -1193,8 +1323,25 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
 #define LONG_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, wc, \
                   (const float4*)weights, h, (int)H, xcn1, xcn2, xij, (const i64*)out_row
   if (max_row_len > LONG_ROW) {
-    if (B <= 4096) hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV, 1024>), dim3((unsigned)B), dim3(1024), 0, st, LONG_ARGS);
-    else hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV, 256>), dim3((unsigned)B), dim3(256), 0, st, LONG_ARGS);
+    if (B <= 4096) {
+      static bool raised_dev[64] = {};        // 2 x 64 KiB of slab: above the default dynamic-LDS limit (attribute is per device)
+      int devid = 0;
+      if (hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < 64 && !raised_dev[devid]) {
+        if (hipFuncSetAttribute((const void*)cn_gather_long_kernel<LPE, NV, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * LONG_SLAB_BYTES(1024)) == hipSuccess) raised_dev[devid] = true;
+      }
+      hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV, 1024>), dim3((unsigned)B), dim3(1024), 2 * LONG_SLAB_BYTES(1024), st, LONG_ARGS);
+    }
+    else {
+      bool by_wave = false;
+      if constexpr (LPE <= 16) {             // narrow embeddings: a wave per hub row, 64 gathers in flight each
+        hipLaunchKernelGGL((cn_gather_wave_kernel<LPE, NV, true>), dim3((unsigned)B), dim3(OCN_WAVE), 0, st, (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst,
+                           (const i64*)order, (i64)B, (const i64*)off, flags, wc, (const float4*)weights, h, (int)H,
+                           xcn1, xcn2, xij, (const i64*)out_row);
+        by_wave = true;
+      }
+      if (!by_wave) hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV, 256>), dim3((unsigned)B), dim3(256), 2 * LONG_SLAB_BYTES(256), st, LONG_ARGS);
+    }
   }
 #undef LONG_ARGS
 }

@@ -107,6 +107,20 @@ __device__ __forceinline__ bool walk_reverse(const i64* __restrict__ nds, i64 i,
   return rev < nds[i];
 }
 
+// Two accumulators that take the same x: (a.x, a.y) += (w.x, w.y) * x on the packed-f32 pipe (v_pk_mul_f32 +
+// v_pk_add_f32: one issue slot for both) — product and sum rounded separately, component for component what the two
+// scalar statements a1 = a1 + w1 * x; a2 = a2 + w2 * x compute.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));      // register arrays carried across loop iterations: the native
+                                                              // vector type is kept in registers where an array of the
+                                                              // float4 struct ends up in scratch
+__device__ __forceinline__ void axpy_pair(f32x2& a, const f32x2 w, const float x) {
+#pragma clang fp contract(off)
+  const f32x2 xx = {x, x};
+  const f32x2 p = w * xx;
+  a = a + p;
+}
+
 __device__ __forceinline__ void axpy4(float4& acc, float w, const float4& x) {
   acc.x = __fadd_rn(acc.x, __fmul_rn(w, x.x));
   acc.y = __fadd_rn(acc.y, __fmul_rn(w, x.y));

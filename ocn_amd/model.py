@@ -783,7 +783,8 @@ class _CNPredictorBase(nn.Module):
     def _heads(self, x, xcn1, xcn2, xij, cls=None):
         if (not self.training and not torch.is_grad_enabled() and xij.is_cuda and xij.dim() == 2 and xij.shape[0] > 0
                 and xij.is_contiguous() and xcn1.is_contiguous() and xcn2.is_contiguous()
-                and xcn1.shape == xij.shape and self._fused_plan(xij.shape[1]) is not None):
+                and xcn1.shape == xij.shape and xij.shape[1] >= ops.fused_heads_min_width
+                and self._fused_plan(xij.shape[1]) is not None):
             return self._heads_fused(xcn1, xcn2, xij, cls)
         if cls is not None:
             return self._heads_skipping(xcn1, xcn2, xij, cls)

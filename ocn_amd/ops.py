@@ -676,6 +676,8 @@ def linear_panel_chained(weight: Tensor) -> Tensor:
 
 HEADS_WIDTHS = (32, 64, 128, 256)
 fused_heads = True               # cn5 / cn7 eval: the whole MLP head as one launch (ocn_heads_fused)
+fused_heads_min_width = 128      # narrower heads (ppa / citation2 / ddi: H = 32..64) have a k-loop of 2-4 steps: the fused
+                                 # kernel's per-tile epilogues dominate and the grouped launches are faster (ddi: 18 vs 31 us)
 
 
 @_on_device

@@ -5,6 +5,7 @@ scores within 1e-5 (atol) + 1e-5 (rtol).
 """
 import json
 import os
+from functools import partial
 from types import SimpleNamespace
 
 import pytest
@@ -1030,6 +1031,41 @@ def test_zero_row_skipping_is_bitwise_neutral(hiplib, name, H, tailact, two):
         finally:
             ops.skip_zero_rows = True
     assert outs[0].shape == (B, 1) and torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("H", [32, 64, 128, 256])
+@pytest.mark.parametrize("ln", [True, False])
+def test_fused_heads_every_width(hiplib, H, ln, monkeypatch):
+    """ocn_heads_fused (one launch for the whole head; the product takes it from ``ops.fused_heads_min_width`` up) at
+    every width it is built for, class ranges on (ragged batch, all four classes present): against the grouped launches
+    and against the torch modules."""
+    from ocn_amd import ops
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    n, B = 3000, 2311
+    oadj = make_graph(n, 5, 60, 43, isolated=20)
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    e = batch(oadj, B, 19).to(DEV)
+    torch.manual_seed(5)
+    x = torch.randn(n, H, device=DEV)
+    pred = partial(predictor_dict["cn5"], cndeg=-1)(H, H, 1, 3, 0.0, 0.0, ln).to(DEV).eval()     # the drivers' head
+    with torch.no_grad():
+        pred.innerprod.fill_(0.5)
+
+    def run():
+        with torch.no_grad():
+            return pred(x, adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e), e, None)
+
+    monkeypatch.setattr(ops, "fused_heads_min_width", 0)
+    assert pred._fused_plan(H) is not None
+    fused = run()
+    monkeypatch.setattr(ops, "fused_heads", False)
+    grouped = run()
+    modules = pred(x, adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e), e, None).detach()   # autograd on: plain torch
+    assert fused.shape == (B, 1)
+    assert close(fused, modules), (fused - modules).abs().max()
+    assert close(grouped, modules), (grouped - modules).abs().max()
 
 
 @pytest.mark.parametrize("name,fin,H", [("cn5", 64, 128), ("cn7", 48, 32), ("cn5", 32, 40)])
