@@ -505,7 +505,7 @@ def main():
                                  "dense f32 MFMA peak it would be priced at without the split.  Head: " + head_layout(pred))
             else:
                 roof = roofs[dom]
-        cpu, err = None, None
+        cpu, err, ref_scale = None, None, None
         if world == 1 and not args.no_cpu_baseline:
             cpu, b, ref = cpu_baseline(wl, args, mines[0])
             ops.validate_indices = False
@@ -514,6 +514,7 @@ def main():
                 c1, c2 = cn_handles(wl, sub)
                 got = pred(h, adj, c1, c2, sub, wl["args"]).cpu()
             err = (got - ref).abs().max().item()
+            ref_scale = ref.abs().max().item()
         idx = {"cora": 0, "collab": 1, "ppa": 2, "citation2": 3, "ddi": 4}[args.dataset]
         line = {
             "metric": f"candidate-edges/sec (CN predictor fwd), ogbl-{args.dataset} shape",
@@ -544,6 +545,8 @@ def main():
             "survey_formula_bytes_per_step": ab["flags_formula"] + ab["gather_formula"],
             "host_enqueue_ms_per_step": t_launch / args.steps * 1e3,
             "parity_on_cpu_sample_max_abs_err": err,
+            "parity_on_cpu_sample_max_abs_ref": ref_scale,         # the scores' scale: raw walk-count pools (citation2) reach 1e4
+            "parity_on_cpu_sample_rel_err": None if not ref_scale else err / ref_scale,
             "score_checksum": float(out.double().sum().item()),
         }
         print(json.dumps(line), flush=True)

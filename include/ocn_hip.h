@@ -215,9 +215,9 @@ int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64
  * union pattern as above; xij[e] = h[i] (.) h[j]; entries in ascending column order, fp32
  * multiply then add.  wc = per-neighbour cn2 values of the walk route or NULL (all 1.0).
  * h is [N][H] row-major fp32; outputs [B][H].  max_row_len = longest row of A (upper bound):
- * batch rows whose source row exceeds 1024 entries are pooled by a whole workgroup, in 256*4/H
- * contiguous segments whose partial sums are added in segment order (everything else keeps the
- * strictly sequential ascending-column sum).  out_row (or NULL): batch row e is written to row
+ * batch rows whose source row exceeds 1024 entries (hubs) are pooled by a whole workgroup — or, for narrow embeddings
+ * in a large batch, a wave — of their own: the other lanes fetch, ONE wave adds, so those rows keep the strictly
+ * sequential ascending-column sum as well.  out_row (or NULL): batch row e is written to row
  * out_row[e] of the three outputs (ocn_class_order's inv_out: class-major rows for the heads).
  * cnt1 / cnt2 (or NULL): the per-row CN counts of the intersection pass; a row with neither kind of
  * entry is not walked at all, and with out_row the xcn1 / xcn2 rows the class-major heads never read

@@ -1,24 +1,26 @@
 #!/bin/bash
-# Round profile refresh (run on the GPU box through gpurun):  bash tools/refresh_profiles.sh r02 [configs...]
-# per config: bench line -> rocprofv3 kernel trace of the same command -> three separate PMC passes
-# (FETCH_SIZE / WRITE_SIZE / TCC hit+miss; never combined with other trace domains).
+# Round profile refresh (run on the GPU box through gpurun):  bash tools/refresh_profiles.sh r02b [configs...]
+# per config: three separate PMC passes (FETCH_SIZE / WRITE_SIZE / TCC hit+miss; never combined with other trace
+# domains) -> their summary into profiles/ (so that the bench line's roofline.traffic is THIS build's) -> the bench line
+# -> rocprofv3 kernel trace of the same command.  Everything lands in gpurun_out/; copy into profiles/ afterwards.
 set -eo pipefail
-R=${1:-r02}; shift || true
+R=${1:-r02b}; shift || true
 CFGS=${@:-collab citation2 ppa ddi cora}
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
 for C in $CFGS; do
   S=""; [ "$C" = collab ] || S="_$C"
-  python bench.py --config $C > $O/${R}_bench_${C}.json 2> $O/${R}_bench_${C}.err
   rm -rf $O/${R}_prof $O/${R}_pmc_fetch $O/${R}_pmc_write $O/${R}_pmc_l2
-  rocprofv3 --kernel-trace --stats -d $O/${R}_prof -o run --output-format csv -- python bench.py --config $C --no-cpu-baseline --no-validate-leg --steps 64 > $O/${R}_bench_prof_${C}.json 2> $O/${R}_prof.err
-  cp $(find $O/${R}_prof -name '*kernel_stats.csv' | head -1) $O/${R}_bench${S}_kernel_stats.csv
   for P in "fetch FETCH_SIZE" "write WRITE_SIZE" "l2 TCC_HIT_sum TCC_MISS_sum"; do
     set -- $P; D=$1; shift
-    rocprofv3 --pmc $@ --kernel-trace -d $O/${R}_pmc_$D -o run --output-format csv -- python bench.py --config $C --no-cpu-baseline --no-validate-leg --no-stage-timers --steps 8 --prewarm 8 > /dev/null 2> $O/${R}_pmc_$D.err
+    timeout -k 10 400 rocprofv3 --pmc $@ --kernel-trace -d $O/${R}_pmc_$D -o run --output-format csv -- python3 bench.py --config $C --no-cpu-baseline --no-validate-leg --no-stage-timers --steps 8 --prewarm 8 > /dev/null 2> $O/${R}_pmc_$D.err
   done
-  python tools/pmc_summary.py $O/${R}_pmc${S}.json $O/${R}_pmc_fetch $O/${R}_pmc_write $O/${R}_pmc_l2
+  python3 tools/pmc_summary.py $O/${R}_pmc${S}.json $O/${R}_pmc_fetch $O/${R}_pmc_write $O/${R}_pmc_l2
+  cp $O/${R}_pmc${S}.json profiles/${R}_pmc${S}.json
+  timeout -k 10 500 python3 bench.py --config $C > $O/${R}_bench_${C}.json 2> $O/${R}_bench_${C}.err
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/${R}_prof -o run --output-format csv -- python3 bench.py --config $C --no-cpu-baseline --no-validate-leg --steps 64 > $O/${R}_bench_prof_${C}.json 2> $O/${R}_prof.err
+  cp $(find $O/${R}_prof -name '*kernel_stats.csv' | head -1) $O/${R}_bench${S}_kernel_stats.csv
   rm -rf $O/${R}_prof $O/${R}_pmc_fetch $O/${R}_pmc_write $O/${R}_pmc_l2      # raw traces: tens of MB, gpurun_out is capped
-  echo "== $C"; head -c 600 $O/${R}_bench_${C}.json; echo
+  echo "== $C"; head -c 400 $O/${R}_bench_${C}.json; echo
 done
