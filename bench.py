@@ -320,6 +320,9 @@ def main():
     ap.add_argument("--prewarm", type=int, default=64, help="untimed runtime pre-warm steps before --warmup")
     ap.add_argument("--run-ahead", type=int, default=6, help="steps the host may enqueue ahead of the GPU")
     ap.add_argument("--timer-every", type=int, default=5, help="record stage events on every n-th timed step")
+    ap.add_argument("--rehearse-collectives", action="store_true",
+                    help="one rank, but with the N > 1 code path: RCCL process group, histogram all-reduce and score "
+                         "all-gather executed (a one-GPU box can then time what the collectives add); not a bench line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -332,6 +335,12 @@ def main():
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
+    elif args.rehearse_collectives:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        import ocn_amd.dist as _d
+        _d.force_collectives = True
 
     from ocn_amd import _lib, ops
     from ocn_amd.dist import gather_scores, shard_bounds
@@ -346,14 +355,21 @@ def main():
     s, e = shard_bounds(B_total, world)[rank]
     mines = [g[:, s:e].contiguous() for g in wl["edges"]]
     NB = len(mines)
-    pred.set_edge_sharding(None, enabled=world > 1)
+    pred.set_edge_sharding(None, enabled=world > 1 or args.rehearse_collectives)
+
+    pending = [None]                               # the previous batch's score all-gather (N > 1), still in flight
 
     def step(it=0):
         with torch.no_grad():
             mine = mines[it % NB]
             c1, c2 = cn_handles(wl, mine)
             loc = pred(h, adj, c1, c2, mine, wl["args"])
-            return gather_scores(loc, B_total)
+            # the scores are consumed after the loop: the all-gather of batch t runs beside batch t + 1 (its own
+            # stream); every one of them has completed when the closing synchronize returns
+            if pending[0] is not None:
+                pending[0].wait()
+            out, pending[0] = gather_scores(loc, B_total, async_op=True)
+            return out
 
     for b in range(NB):                            # every batch validated once (bounds check + flag capacity)
         out = step(b)
@@ -413,6 +429,9 @@ def main():
                 timer.mark("mlp_glue")
             ring[it % run_ahead].record()
         t_launch = time.perf_counter() - t0 - t_wait    # host time spent enqueueing (flow-control waits excluded)
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -552,6 +571,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -161,6 +161,9 @@ struct Heads {
 
   // acc[t][i] += v[feature]
   static __device__ __forceinline__ void add_vec(f32x16 (&acc)[NT], const float* v, int hh) {
+#ifdef OCN_X_HD_NOEPI   /* timing experiment: the cost of the register epilogues */
+    pin(acc); return;
+#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -173,6 +176,9 @@ struct Heads {
 
   // LayerNorm over the H features of every candidate (a candidate's features: the 16 NT registers of lanes r, r+32)
   static __device__ __forceinline__ void layer_norm(f32x16 (&acc)[NT], const float* g, const float* b, float eps, int hh) {
+#ifdef OCN_X_HD_NOEPI
+    pin(acc); return;
+#endif
     float s = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -202,6 +208,9 @@ struct Heads {
   }
 
   static __device__ __forceinline__ void relu(f32x16 (&acc)[NT]) {
+#ifdef OCN_X_HD_NOEPI
+    pin(acc); return;
+#endif
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -396,6 +405,10 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
       chained_layer(l1, l2);
       float4* pk = park + (size_t)br * (NT * 4) * 64;
       asm volatile("" : "+v"(pk));           // (or every one of the 2 x 4 NT addresses is precomputed outside the tile loop and kept)
+#ifdef OCN_X_HD_NOPARK  /* timing experiment: the cost of parking a branch's share in memory */
+      HD::pin(l1);
+      if (false)
+#endif
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -427,8 +440,13 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int fo = 32 * t + 8 * g + 4 * hh;
+#ifdef OCN_X_HD_NOPARK
+          const float4 sa = *reinterpret_cast<const float4*>(s_vec + V_CA * H + fo);
+          const float4 sb = *reinterpret_cast<const float4*>(s_vec + V_CB * H + fo);
+#else
           const float4 sa = wgA ? pa[g * 64] : *reinterpret_cast<const float4*>(s_vec + V_CA * H + fo);
           const float4 sb = wgB ? pb[g * 64] : *reinterpret_cast<const float4*>(s_vec + V_CB * H + fo);
+#endif
           const float4 bf = *reinterpret_cast<const float4*>(s_vec + V_BF * H + fo);
           l2[t][4 * g + 0] = ((sa.x + sb.x) + l2[t][4 * g + 0]) + bf.x;
           l2[t][4 * g + 1] = ((sa.y + sb.y) + l2[t][4 * g + 1]) + bf.y;

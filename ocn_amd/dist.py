@@ -59,6 +59,31 @@ def allreduce_hist(hist: Tensor, group=None, valued: bool = True) -> Tensor:
     return hist
 
 
+def allreduce_hist_start(hist: Tensor, group=None, valued: bool = True):
+    """``allreduce_hist`` split in two so that work which does not read the histogram (the class ordering of the batch
+    rows) runs between them: on RCCL the collective is enqueued asynchronously (its own stream, ordered after the
+    kernels already on the current one) and a handle is returned for ``allreduce_hist_finish``; gloo rehearsals and the
+    one-rank case finish here and return None."""
+    if _solo(group):
+        return None
+    buf = hist if valued else hist[:, 0].contiguous()
+    if _host_staged(buf, group) or not buf.is_cuda:
+        allreduce_hist(hist, group, valued)
+        return None
+    work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return work, buf, hist, valued
+
+
+def allreduce_hist_finish(handle) -> None:
+    """Make the current stream wait for the histogram sum started by ``allreduce_hist_start``."""
+    if handle is None:
+        return
+    work, buf, hist, valued = handle
+    work.wait()                                  # a stream dependency, not a host wait
+    if not valued:
+        hist[:, 0].copy_(buf)
+
+
 def ring_colsum(run, n_cols: int, device, group=None) -> Tensor:
     """Order-exact S2 of an edge-sharded cn5 batch (innerprod != 0).  The reference adds a column's entries in
     ascending batch-row order (model.py:2405-2406) and the shards are contiguous row ranges, so the sum is a chain
@@ -94,10 +119,19 @@ def check_global_batch(total: int) -> None:
         raise ValueError(f"global candidate batch of {total} edges exceeds the histogram field width ({MAX_BATCH})")
 
 
-def gather_scores(local: Tensor, total: int, group=None) -> Tensor:
-    """All-gather the per-edge scores of every shard back into batch order: [total, C]."""
+def gather_scores(local: Tensor, total: int, group=None, async_op: bool = False):
+    """All-gather the per-edge scores of every shard back into batch order: [total, C].
+    ``async_op`` (RCCL, equal slices): returns ``(out, work)`` with the collective still in flight — a scoring loop
+    that only consumes the scores later (``bench.py``, ``pipeline.score_edges``) calls ``work.wait()`` then, and the next
+    batch's kernels do not queue behind this batch's all-gather."""
     if _solo(group):
-        return local
+        return (local, None) if async_op else local
+    if async_op:
+        world = dist.get_world_size(group)
+        if total % world == 0 and local.is_contiguous() and not _host_staged(local, group) and local.is_cuda:
+            out = local.new_empty((total,) + tuple(local.shape[1:]))
+            return out, dist.all_gather_into_tensor(out, local, group=group, async_op=True)
+        return gather_scores(local, total, group), None
     world = dist.get_world_size(group)
     bounds = shard_bounds(total, world)
     width = max(e - s for s, e in bounds)

@@ -463,13 +463,30 @@ class _CNPredictorBase(nn.Module):
         column histograms over ``group`` (RCCL all-reduce) before normalising (ocn_amd.dist)."""
         self._shard_group, self._sharded = group, enabled
 
-    def _exchange(self, st):
+    def _exchange(self, st, x=None):
+        """Edge-sharded batches: sum the column histograms over the ranks.  The collective is started, the class
+        ordering of the batch rows (which reads the per-row counts only) is enqueued beside it, then the current stream
+        waits for the sum."""
         if self._sharded:
-            from .dist import allreduce_hist
-            allreduce_hist(st.hist, self._shard_group, valued=st.walk)
+            from .dist import allreduce_hist_finish, allreduce_hist_start
+            handle = allreduce_hist_start(st.hist, self._shard_group, valued=st.walk)
             st.sharded, st.shard_group = True, self._shard_group
+            if x is not None:
+                self._class_order(st, x)
+            allreduce_hist_finish(handle)
             ops._mark("allreduce_hist")
         return st
+
+    def _class_order(self, st, x) -> None:
+        """Class-major rows (candidates without cn1 / cn2 entries end up in contiguous ranges the heads skip) where
+        that pays; sets ``st.cls`` (None = batch order)."""
+        st.cls = None
+        st._cls_decided = True
+        if (ops.skip_zero_rows and not self.training and not torch.is_grad_enabled() and st.B >= ops.skip_zero_min_batch
+                and st.cnt2 is not None and (self._fused_plan(x.shape[1]) is not None or self._heads_plan(x.shape[1]) is not None)
+                and self._skip_worthwhile()):
+            st.cls = ops.class_order(st.cnt1, st.cnt2, st.order, st.ws)
+            self._skip_probe(st.cls[2], st.B)
 
     def _scratch(self, x):
         """Reuse scratch across batches only where nothing outlives the call: no autograd graph (it
@@ -480,15 +497,11 @@ class _CNPredictorBase(nn.Module):
         x = x.contiguous()
         if torch.is_grad_enabled() and x.requires_grad:
             return _PoolFn.apply(x, st, w)
-        st.cls = None
-        if (ops.skip_zero_rows and not self.training and not torch.is_grad_enabled() and st.B >= ops.skip_zero_min_batch
-                and st.cnt2 is not None and (self._fused_plan(x.shape[1]) is not None or self._heads_plan(x.shape[1]) is not None)
-                and self._skip_worthwhile()):
-            # class-major rows: candidates without cn1 / cn2 entries end up in contiguous ranges the heads skip
+        if not getattr(st, "_cls_decided", False):
+            self._class_order(st, x)
+        if st.cls is not None:
             # (the pooling keeps its own source-sorted, XCD-balanced processing order and only WRITES to the
             # class-major rows: processed class-major, the XCDs holding the heavy classes ran 50 % longer)
-            st.cls = ops.class_order(st.cnt1, st.cnt2, st.order, st.ws)
-            self._skip_probe(st.cls[2], st.B)
             return st.gather(w, x, out_row=st.cls[1])
         return st.gather(w, x)
 
@@ -813,7 +826,7 @@ class CNLinkPredictorOringin(_CNPredictorBase):
 
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
-        st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x), adj=adj))
+        st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x), adj=adj), x)
         w = st.weights_cn5(self.innerprod1(st))
         xcn1, xcn2, xij = self._pool(st, w, x)
         return self._heads(x, xcn1, xcn2, xij, getattr(st, "cls", None))
@@ -829,7 +842,7 @@ class CNLinkPredictorbaselearn(_CNPredictorBase):
 
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, args, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
-        st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x), adj=adj))
+        st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x), adj=adj), x)
         w = st.weights_cn7(float(args.sum))
         xcn1, xcn2, xij = self._pool(st, w, x)
         return self._heads(x, xcn1, xcn2, xij, getattr(st, "cls", None))

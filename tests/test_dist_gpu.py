@@ -93,9 +93,21 @@ def _rccl_worker(port, q):
                     from ocn_amd.dist import gather_scores
                     loc = p(h, adj, adjoverlap(adj, adj, edges), adjoverlap(adj, adj2, edges), edges, args)
                     out = gather_scores(loc, edges.shape[1])
+                    # the scoring loop's form: the all-gather of batch t in flight beside batch t + 1
+                    pend, outs = None, []
+                    for _ in range(3):
+                        loc = p(h, adj, adjoverlap(adj, adj, edges), adjoverlap(adj, adj2, edges), edges, args)
+                        if pend is not None:
+                            pend.wait()
+                        o, pend = gather_scores(loc, edges.shape[1], async_op=True)
+                        outs.append(o)
+                    if pend is not None:
+                        pend.wait()
+                    torch.cuda.synchronize()
                 finally:
                     p.set_edge_sharding(None, enabled=False)
                 ok[k] = bool(torch.equal(out, single))
+                ok[k + "_async"] = all(bool(torch.equal(o, single)) for o in outs)
         t = torch.ones(1 << 20, device=dev)
         dist.all_reduce(t)
         ok["allreduce"] = bool((t == 1).all())
