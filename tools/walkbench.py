@@ -17,10 +17,10 @@ def child():
     import bench
     from ocn_amd import ops
     from ocn_amd.utils import CNState
-    args = argparse.Namespace(dataset=os.environ["KB_DATASET"], scale=1.0, hiddim=None, predictor=None, batch=None)
+    args = argparse.Namespace(dataset=os.environ["KB_DATASET"], scale=1.0, hiddim=None, predictor=None, batch=None, batches=1, innerprod=0.0)
     dev = torch.device("cuda:0")
     wl = bench.build_workload(args, dev, 0, 1)
-    adj, e = wl["adj"], wl["edges"]
+    adj, e = wl["adj"], wl["edges"][0]
     ops.validate_indices = False
     out = []
     for two in (False, True):
