@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define OCN_ABI_VERSION 3
+#define OCN_ABI_VERSION 4
 #define OCN_EINVAL (-1)   /* null pointer / negative size / unsupported combination */
 #define OCN_ECAP   (-2)   /* reported through the device status word: flags capacity too small */
 
@@ -64,6 +64,16 @@ int ocn_check_edges(const int64_t* src, const int64_t* dst, int64_t B, int64_t n
 int64_t ocn_order_workspace_bytes(int64_t n_nodes);
 int ocn_order_by_node(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* order, void* workspace,
                       void* stream);
+
+/* One launch for everything in front of the intersection pass of a large batch: the flag offsets (ocn_edge_offsets), the
+ * counting phase of ocn_order_by_node (order_workspace, or NULL: no processing order) and the batch's resets
+ * (ocn_zero_regions' arguments) — the two latter ride on extra workgroups of the scan's launch.  Follow with
+ * ocn_order_by_node_finish (scan of the counters + scatter) for the order itself.  Workspaces: ZERO on entry, left zero. */
+int ocn_batch_prep(const int64_t* rowptrA, const int64_t* src, int64_t B, int64_t* off /* [B+1] */, void* scan_workspace,
+                   int64_t n_nodes, void* order_workspace /* or NULL */, void* const* zero_ptrs, const int64_t* zero_bytes,
+                   int32_t n_zero, void* stream);
+int ocn_order_by_node_finish(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* order, void* workspace,
+                             void* stream);
 
 /* Forward work-item offsets of the walk route: out[slot] = number of items of the earlier processing
  * slots, out[B] = number of items.  A batch row's items are groups of consecutive chunks of

@@ -19,7 +19,7 @@ INCLUDE = os.path.join(_ROOT, "include")
 
 # name -> (restype, argtypes); must list every symbol include/ocn_hip.h declares
 _P = c_void_p
-ABI_VERSION = 3
+ABI_VERSION = 4
 SIGNATURES = {
     "ocn_abi_version": (c_int32, []),
     "ocn_scan_workspace_bytes": (c_int64, [c_int64]),
@@ -30,6 +30,8 @@ SIGNATURES = {
     "ocn_scan_i32": (c_int32, [_P, c_int64, _P, _P, _P]),
     "ocn_order_workspace_bytes": (c_int64, [c_int64]),
     "ocn_order_by_node": (c_int32, [_P, c_int64, c_int64, _P, _P, _P]),
+    "ocn_order_by_node_finish": (c_int32, [_P, c_int64, c_int64, _P, _P, _P]),
+    "ocn_batch_prep": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int32, _P]),
     "ocn_cn_flags": (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int64, _P, _P, c_int64, _P,
                                _P, _P, _P, _P]),
     "ocn_chunk_offsets": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P]),

@@ -114,6 +114,40 @@ __global__ __launch_bounds__(OCN_BLOCK) void scan_single(Op op, i64 n, i64* out)
   if (threadIdx.x == 0) out[n] = carry;
 }
 
+// several small scratch arrays zeroed by ONE launch (a candidate batch resets its histogram, counters and status
+// words: as separate fills that was four launches of a few microseconds each)
+#define ZERO_MAX_REGIONS 8
+struct ZeroArgs { int n; uint32_t* p[ZERO_MAX_REGIONS]; i64 words[ZERO_MAX_REGIONS]; };
+// (vb, vg): this workgroup's index among the vg workgroups that share the job
+__device__ __forceinline__ void zero_body(const ZeroArgs& a, i64 vb, i64 vg) {
+  i64 total = 0;
+  for (int r = 0; r < a.n; ++r) total += (a.words[r] + 3) >> 2;          // in 16-byte quads
+  for (i64 q = vb * blockDim.x + threadIdx.x; q < total; q += vg * blockDim.x) {
+    i64 o = q;
+    int r = 0;
+    while (o >= ((a.words[r] + 3) >> 2)) { o -= (a.words[r] + 3) >> 2; ++r; }
+    uint32_t* base = a.p[r] + 4 * o;
+    const i64 left = a.words[r] - 4 * o;
+    if (left >= 4 && ((uintptr_t)base & 15) == 0) *reinterpret_cast<uint4*>(base) = make_uint4(0u, 0u, 0u, 0u);
+    else for (int k = 0; k < 4 && k < left; ++k) base[k] = 0u;
+  }
+}
+__device__ __forceinline__ void order_count_body(const i64* __restrict__ node, i64 B, int32_t* __restrict__ counts, i64 vb, i64 vg) {
+  for (i64 e = vb * blockDim.x + threadIdx.x; e < B; e += vg * blockDim.x) atomicAdd(counts + node[e], 1);
+}
+// Work that needs nothing from the scan, carried by extra workgroups of the scan's launch (blockIdx >= number of
+// tiles): a batch's resets and the counting phase of its processing order cost no launch of their own.
+struct NoExtra { __device__ __forceinline__ void operator()(i64, i64) const {} };
+struct PrepExtra {
+  ZeroArgs z;
+  i64 zero_blocks;
+  const i64* node; i64 B; int32_t* counts;       // counts == NULL: no processing order wanted
+  __device__ __forceinline__ void operator()(i64 vb, i64 vg) const {
+    if (vb < zero_blocks) zero_body(z, vb, zero_blocks);
+    else if (counts) order_count_body(node, B, counts, vb - zero_blocks, vg - zero_blocks);
+  }
+};
+
 // Large inputs: ONE launch, tiles chained through device memory.  A workgroup draws its tile from a ticket
 // (so every predecessor tile has started, whatever the dispatch order), publishes its tile total as one 8-byte
 // granule {ready bit | total} (relaxed agent-scope store: the granule carries its own tag, no fence), and wave 0
@@ -122,11 +156,15 @@ __global__ __launch_bounds__(OCN_BLOCK) void scan_single(Op op, i64 n, i64* out)
 // caller zeroes it once, when it allocates it).  state[0] = ticket, state[1] = finished tiles, state[2 + t] = tile t.
 #define SCAN_READY (1ull << 63)
 #define SCAN_SPIN_MAX (1 << 22)     /* bounded polling: a stale workspace gives wrong numbers, never a hang */
-template <typename Op>
+template <typename Op, typename Extra = NoExtra>
 __global__ __launch_bounds__(OCN_BLOCK) void scan_chained(Op op, i64 n, i64* __restrict__ out, u64* __restrict__ state,
-                                                          i64 nt) {
+                                                          i64 nt, const Extra extra = Extra()) {
   __shared__ i64 sh[2 * OCN_WPB];
   __shared__ i64 s_tile, s_prefix;
+  if ((i64)blockIdx.x >= nt) {               // (uniform per workgroup; these draw no tile ticket)
+    extra((i64)blockIdx.x - nt, (i64)gridDim.x - nt);
+    return;
+  }
   if (threadIdx.x == 0) s_tile = (i64)atomicAdd(&state[0], 1ull);
   __syncthreads();
   const i64 t = s_tile;
@@ -186,7 +224,7 @@ static int run_scan(Op op, i64 n, i64* out, void* ws, hipStream_t st) {
     return launch_status();
   }
   const i64 nt = (n + SCAN_TILE - 1) / SCAN_TILE;
-  hipLaunchKernelGGL(scan_chained<Op>, dim3((unsigned)nt), dim3(OCN_BLOCK), 0, st, op, n, out, (u64*)ws, nt);
+  hipLaunchKernelGGL((scan_chained<Op, NoExtra>), dim3((unsigned)nt), dim3(OCN_BLOCK), 0, st, op, n, out, (u64*)ws, nt, NoExtra());
   return launch_status();
 }
 
@@ -197,8 +235,7 @@ static int run_scan(Op op, i64 n, i64* out, void* ws, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(OCN_BLOCK) void order_count(const i64* __restrict__ node, i64 B,
                                                          int32_t* __restrict__ counts) {
-  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < B; e += (i64)gridDim.x * blockDim.x)
-    atomicAdd(counts + node[e], 1);
+  order_count_body(node, B, counts, (i64)blockIdx.x, (i64)gridDim.x);
 }
 
 // (the counters were consumed by the scan: each row clears the one it raised, so the workspace is left zero)
@@ -222,41 +259,35 @@ __global__ __launch_bounds__(OCN_BLOCK) void check_edges_kernel(const i64* __res
   if (__ballot(b) && (threadIdx.x & 63) == 0) atomicOr(bad, 1);
 }
 
-// several small scratch arrays zeroed by ONE launch (a candidate batch resets its histogram, counters and status
-// words: as separate fills that was four launches of a few microseconds each)
-#define ZERO_MAX_REGIONS 8
-struct ZeroArgs { int n; uint32_t* p[ZERO_MAX_REGIONS]; i64 words[ZERO_MAX_REGIONS]; };
 __global__ __launch_bounds__(OCN_BLOCK) void zero_regions_kernel(const ZeroArgs a) {
-  i64 total = 0;
-  for (int r = 0; r < a.n; ++r) total += (a.words[r] + 3) >> 2;          // in 16-byte quads
-  for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (i64)gridDim.x * blockDim.x) {
-    i64 o = q;
-    int r = 0;
-    while (o >= ((a.words[r] + 3) >> 2)) { o -= (a.words[r] + 3) >> 2; ++r; }
-    uint32_t* base = a.p[r] + 4 * o;
-    const i64 left = a.words[r] - 4 * o;
-    if (left >= 4 && ((uintptr_t)base & 15) == 0) *reinterpret_cast<uint4*>(base) = make_uint4(0u, 0u, 0u, 0u);
-    else for (int k = 0; k < 4 && k < left; ++k) base[k] = 0u;
-  }
+  zero_body(a, (i64)blockIdx.x, (i64)gridDim.x);
 }
 
-extern "C" {
-
-int64_t ocn_scan_workspace_bytes(int64_t n);
-
-int ocn_zero_regions(void* const* ptrs, const int64_t* bytes, int32_t n, void* stream) {
-  if (n < 0 || n > ZERO_MAX_REGIONS || (n > 0 && (!ptrs || !bytes))) return OCN_EINVAL;
-  ZeroArgs a;
+// (ptrs, bytes) -> ZeroArgs; returns the number of 16-byte quads, or -1 for bad arguments
+static i64 zero_args(void* const* ptrs, const int64_t* bytes, int32_t n, ZeroArgs& a) {
+  if (n < 0 || n > ZERO_MAX_REGIONS || (n > 0 && (!ptrs || !bytes))) return -1;
   a.n = 0;
   i64 quads = 0;
   for (int r = 0; r < n; ++r) {
-    if (bytes[r] < 0 || (bytes[r] & 3) || (bytes[r] > 0 && (!ptrs[r] || ((uintptr_t)ptrs[r] & 3)))) return OCN_EINVAL;
+    if (bytes[r] < 0 || (bytes[r] & 3) || (bytes[r] > 0 && (!ptrs[r] || ((uintptr_t)ptrs[r] & 3)))) return -1;
     if (bytes[r] == 0) continue;
     a.p[a.n] = (uint32_t*)ptrs[r];
     a.words[a.n] = bytes[r] >> 2;
     quads += (a.words[a.n] + 3) >> 2;
     ++a.n;
   }
+  return quads;
+}
+
+extern "C" {
+
+int64_t ocn_scan_workspace_bytes(int64_t n);
+int ocn_order_by_node_finish(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* order, void* workspace, void* stream);
+
+int ocn_zero_regions(void* const* ptrs, const int64_t* bytes, int32_t n, void* stream) {
+  ZeroArgs a;
+  const i64 quads = zero_args(ptrs, bytes, n, a);
+  if (quads < 0) return OCN_EINVAL;
   if (a.n == 0) return 0;
   hipLaunchKernelGGL(zero_regions_kernel, dim3(grid_for((quads + OCN_BLOCK - 1) / OCN_BLOCK, 2048)), dim3(OCN_BLOCK), 0,
                      (hipStream_t)stream, a);
@@ -292,11 +323,53 @@ int ocn_order_by_node(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* 
 #endif
   const int grid = grid_for((B + OCN_BLOCK - 1) / OCN_BLOCK, 1024);
   hipLaunchKernelGGL(order_count, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)node, (i64)B, counts);
+  return ocn_order_by_node_finish(node, B, n_nodes, order, workspace, stream);
+}
+
+int ocn_order_by_node_finish(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* order, void* workspace,
+                             void* stream) {
+  if (B < 0 || n_nodes <= 0) return OCN_EINVAL;
+  if (B == 0) return 0;
+  if (!node || !order || !workspace) return OCN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* counts = (int32_t*)workspace;
+  i64* offs = (i64*)((char*)workspace + order_counts_bytes(n_nodes));
+  void* scan_ws = (void*)(offs + n_nodes + 1);
+  const int grid = grid_for((B + OCN_BLOCK - 1) / OCN_BLOCK, 1024);
   I32In op{counts};
   int rc = run_scan(op, (i64)n_nodes, offs, scan_ws, st);
   if (rc) return rc;
   hipLaunchKernelGGL(order_scatter, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)node, (i64)B,
                      (unsigned long long*)offs, (i64*)order, counts);
+  return launch_status();
+}
+
+int ocn_batch_prep(const int64_t* rowptrA, const int64_t* src, int64_t B, int64_t* off, void* scan_workspace,
+                   int64_t n_nodes, void* order_workspace, void* const* zero_ptrs, const int64_t* zero_bytes,
+                   int32_t n_zero, void* stream) {
+  if (B < 0 || !rowptrA || (!src && B > 0) || !off || !scan_workspace || (order_workspace && n_nodes <= 0)) return OCN_EINVAL;
+  ZeroArgs z;
+  const i64 quads = zero_args(zero_ptrs, zero_bytes, n_zero, z);
+  if (quads < 0) return OCN_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  DegOfSrc op{(const i64*)rowptrA, (const i64*)src};
+  int32_t* counts = (int32_t*)order_workspace;
+  if (B <= SCAN_SINGLE_MAX) {                // small batch: the single-workgroup scan has no extra workgroups to lend
+    int rc = ocn_zero_regions(zero_ptrs, zero_bytes, n_zero, stream);
+    if (rc) return rc;
+    if (counts && B > 0)
+      hipLaunchKernelGGL(order_count, dim3(grid_for((B + OCN_BLOCK - 1) / OCN_BLOCK, 1024)), dim3(OCN_BLOCK), 0, st,
+                         (const i64*)src, (i64)B, counts);
+    return run_scan(op, (i64)B, (i64*)off, scan_workspace, st);
+  }
+  const i64 nt = (B + SCAN_TILE - 1) / SCAN_TILE;
+  PrepExtra x;
+  x.z = z;
+  x.zero_blocks = z.n ? grid_for((quads + OCN_BLOCK - 1) / OCN_BLOCK, 1024) : 0;
+  x.node = (const i64*)src; x.B = (i64)B; x.counts = counts;
+  const i64 count_blocks = counts ? grid_for((B + OCN_BLOCK - 1) / OCN_BLOCK, 512) : 0;
+  hipLaunchKernelGGL((scan_chained<DegOfSrc, PrepExtra>), dim3((unsigned)(nt + x.zero_blocks + count_blocks)), dim3(OCN_BLOCK), 0, st,
+                     op, (i64)B, (i64*)off, (u64*)scan_workspace, nt, x);
   return launch_status();
 }
 

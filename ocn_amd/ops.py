@@ -201,24 +201,31 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
         return _cn_flags_walk_small(rowptrA, colA, src, dst, n_cols, max_deg_a, wsd, nds)
     # processing order: candidates with the same / nearby source node share most of the rows they
     # gather, so visiting them together turns HBM row fetches into L2 hits (outputs stay in batch order)
-    order = None
-    if B >= sort_edges_min_batch:
-        order = buf(wsd, "order", B, torch.int64, dev)
-        n_src = rowptrA.numel() - 1
-        ows = buf(wsd, "order_ws", int(_lib.lib().ocn_order_workspace_bytes(n_src)) // 8 + 1, torch.int64, dev, zero_init=True)
-        check(_lib.lib().ocn_order_by_node(ptr(src), B, n_src, ptr(order), ptr(ows), stream_ptr()),
-              "ocn_order_by_node")
-    off = edge_offsets(rowptrA, src, wsd)
-    bound = B * max(int(max_deg_a), 0)
-    cap = bound if bound <= FLAGS_NOSYNC_LIMIT else int(off[-1].item())
-    flags = buf(wsd, "flags", max(cap, 1), torch.uint8, dev)
-    wc = buf(wsd, "wc", max(cap, 1), torch.int32, dev) if walk else None
+    want_order = B >= sort_edges_min_batch
+    n_src = rowptrA.numel() - 1
+    order = buf(wsd, "order", B, torch.int64, dev) if want_order else None
+    ows = (buf(wsd, "order_ws", int(_lib.lib().ocn_order_workspace_bytes(n_src)) // 8 + 1, torch.int64, dev, zero_init=True)
+           if want_order else None)
+    off = buf(wsd, "off", B + 1, torch.int64, dev)
+    sws = buf(wsd, "scan_ws", int(_lib.lib().ocn_scan_workspace_bytes(B)) // 8 + 1, torch.int64, dev, zero_init=True)
     hist = buf(wsd, "hist", (n_cols, 2), torch.int64, dev)
     cnt1 = buf(wsd, "cnt1", B, torch.int32, dev)
     cnt2 = buf(wsd, "cnt2", B, torch.int32, dev) if (walk or t2 is not None) else None
     status = buf(wsd, "status", 4, torch.int32, dev)     # [0] overflow flag; [1], [2] walk-route work tickets
     scal = buf(wsd, "scal", 4, torch.int32, dev)         # the column statistics word of the weights stage
-    zero_regions([hist, status, scal] + ([cnt1, cnt2] if walk else []))      # the batch's reset: one launch
+    # the flag offsets, the counting phase of the order and the batch's resets: ONE launch (ocn_batch_prep)
+    zs = [t for t in [hist, status, scal] + ([cnt1, cnt2] if walk else []) if t is not None and t.numel()]
+    zp = (ctypes.c_void_p * len(zs))(*[t.data_ptr() for t in zs])
+    zb = (ctypes.c_int64 * len(zs))(*[t.numel() * t.element_size() for t in zs])
+    check(_lib.lib().ocn_batch_prep(ptr(rowptrA), ptr(src), B, ptr(off), ptr(sws), n_src, ptr(ows), zp, zb, len(zs),
+                                    stream_ptr()), "ocn_batch_prep")
+    if want_order:
+        check(_lib.lib().ocn_order_by_node_finish(ptr(src), B, n_src, ptr(order), ptr(ows), stream_ptr()),
+              "ocn_order_by_node_finish")
+    bound = B * max(int(max_deg_a), 0)
+    cap = bound if bound <= FLAGS_NOSYNC_LIMIT else int(off[-1].item())
+    flags = buf(wsd, "flags", max(cap, 1), torch.uint8, dev)
+    wc = buf(wsd, "wc", max(cap, 1), torch.int32, dev) if walk else None
     chunk_off = rev_off = None
     if walk:
         if nds is not None and walk_two_sided:
