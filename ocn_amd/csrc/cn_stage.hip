@@ -40,6 +40,7 @@ __device__ __forceinline__ bool sampled_has(const int32_t* samp, const int32_t* 
 // K1 (pattern): flags for N(src) against the rows of dst in T1 (and T2)
 // ---------------------------------------------------------------------------------------------
 #define T1_CAP 1024
+#define REC_LEN_SHIFT 40                     /* slot record word 2: row start (nnz < 2^40) | row length << 40 */
 #ifndef OCN_X_G
 #define OCN_X_G 64     /* lanes per candidate edge; tools/kbench.py overrides it for timing experiments */
 #endif
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     i64 n_cols, const i64* __restrict__ off, uint8_t* __restrict__ flags, i64 cap,
     u64* __restrict__ hist, int32_t* __restrict__ cnt1, int32_t* __restrict__ cnt2,
-    int32_t* __restrict__ status) {
+    int32_t* __restrict__ status, u64* __restrict__ rec) {
   constexpr int GPB = OCN_BLOCK / G;
   __shared__ int32_t s_t1[GPB][T1_CAP];
   __shared__ int32_t s_t2[GPB][OCN_WAVE];
@@ -146,6 +147,14 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     if (act && gl == 0) {
       cnt1[e] = c1;
       if (cnt2) cnt2[e] = c2;
+      if (rec) {                              // what the pooling needs to know about this slot, in ONE 32-byte record
+        const i64 i = src[e], j = dst[e];
+        u64* r = rec + 4 * slot;
+        r[0] = (u64)e;
+        r[1] = (u64)i | ((u64)j << 32);
+        r[2] = (u64)a0 | ((u64)da << REC_LEN_SHIFT);
+        r[3] = (u64)base | ((u64)(c1 > 0) << 62) | ((u64)(c2 > 0) << 63);
+      }
     }
     __syncthreads();
   }
@@ -732,7 +741,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
     float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij,
     const i64* __restrict__ out_row,     // out_row[batch row] = output row (class-major heads), or NULL
-    const int32_t* __restrict__ cnt1, const int32_t* __restrict__ cnt2) {   // per-row CN counts, or NULL
+    const int32_t* __restrict__ cnt1, const int32_t* __restrict__ cnt2,     // per-row CN counts, or NULL
+    const u64* __restrict__ rec) {       // slot records of the intersection pass (then order/src/dst/off/cnt are not read), or NULL
   constexpr int GPW = OCN_WAVE / LPE;
   const int lane = threadIdx.x & 63;
   const int gl = lane % LPE;
@@ -752,9 +762,25 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
   }
   const i64 slot = (bid * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
   if (slot >= B) return;                    // whole group leaves together
-  const i64 e = order ? order[slot] : slot;
-  const i64 i = src[e], j = dst[e];
-  const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+  // One dependent load instead of three (order -> src / dst / off / counts -> rowptr) in front of the first gather:
+  // the intersection pass left everything about this slot in a 32-byte record.
+  i64 e, i, j, a0, da, base;
+  bool has1, has2;
+  if (rec) {
+    const ulonglong2* rp = reinterpret_cast<const ulonglong2*>(rec + 4 * slot);
+    const ulonglong2 ra = rp[0], rb = rp[1];
+    e = (i64)ra.x; i = (i64)(ra.y & 0xffffffffull); j = (i64)(ra.y >> 32);
+    a0 = (i64)(rb.x & ((1ull << REC_LEN_SHIFT) - 1)); da = (i64)(rb.x >> REC_LEN_SHIFT);
+    base = (i64)(rb.y & ((1ull << 62) - 1)); has1 = (rb.y >> 62) & 1ull; has2 = rb.y >> 63;
+  } else {
+    e = order ? order[slot] : slot;
+    i = src[e]; j = dst[e];
+    a0 = rowptrA[i]; da = rowptrA[i + 1] - a0;
+    base = off[e];
+    // a candidate without any CN entry (half of an evaluation batch) has nothing to pool; with class-major
+    // output rows the heads never read its xcn1 / xcn2 rows (nor the xcn1 row of one without cn1 entries)
+    has1 = !cnt1 || cnt1[e] > 0; has2 = !cnt2 || cnt2[e] > 0;
+  }
   if (da > LONG_ROW) return;                // cn_gather_long_kernel's
   const float4* h4 = reinterpret_cast<const float4*>(h) + slice * (LPE * NV);
   const i64 rowq = H >> 2;                  // float4 per row
@@ -762,10 +788,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
   float4 acc1[NV], acc2[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  // a candidate without any CN entry (half of an evaluation batch) has nothing to pool; with class-major
-  // output rows the heads never read its xcn1 / xcn2 rows (nor the xcn1 row of one without cn1 entries)
-  const bool has1 = !cnt1 || cnt1[e] > 0, has2 = !cnt2 || cnt2[e] > 0;
-  if (has1 | has2) pool_range<LPE, NV>(0, da, a0, off[e], gl, gbase, colA, flags, wc, weights, h4, rowq, acc1, acc2);
+  if (has1 | has2) pool_range<LPE, NV>(0, da, a0, base, gl, gbase, colA, flags, wc, weights, h4, rowq, acc1, acc2);
   pool_store<LPE, NV>(out_row ? out_row[e] : e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij,
                       !out_row || has1, !out_row || has1 || has2);
 }
@@ -1285,7 +1308,7 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
                           const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
                           const int32_t* wc, const float* weights, const float* h, int32_t H, int64_t max_row_len,
                           float* xcn1, float* xcn2, float* xij, const int64_t* out_row, const int32_t* cnt1,
-                          const int32_t* cnt2, hipStream_t st) {
+                          const int32_t* cnt2, const uint64_t* rec, hipStream_t st) {
   const i64 epb = (i64)OCN_WPB * (OCN_WAVE / LPE);
   bool packed = true;
   if constexpr (LPE <= 16) {
@@ -1299,7 +1322,7 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
   }
 #define PACKED_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, \
                     (const i64*)off, flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij,           \
-                    (const i64*)out_row, cnt1, cnt2
+                    (const i64*)out_row, cnt1, cnt2, (const u64*)rec
   if (packed) {
     bool sliced = false;
 #ifdef OCN_X_SLICE
@@ -1353,7 +1376,7 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
                  const uint32_t* bitmapT1, int64_t bm1_stride_words, const uint32_t* bitmapT2, int64_t bm_stride_words,
                  const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                  int64_t n_cols, const int64_t* off, uint8_t* flags, int64_t flags_cap, uint64_t* hist,
-                 int32_t* cnt1, int32_t* cnt2, int32_t* status, void* stream) {
+                 int32_t* cnt1, int32_t* cnt2, int32_t* status, uint64_t* rec, void* stream) {
   if (B < 0 || flags_cap < 0 || B > (int64_t)HF_MASK) return OCN_EINVAL;
   if (B == 0) return 0;
   if (!rowptrA || (!rowptrT1 && !bitmapT1) || !src || !dst || !off || !hist || !cnt1 || !status) return OCN_EINVAL;
@@ -1386,7 +1409,7 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
   (const i64*)rowptrA, colA, (const i64*)rowptrT1, colT1, (const i64*)(T2P), (T2C),                   \
       (const unsigned*)bitmapT1, (i64)bm1_stride_words, (const unsigned*)bitmapT2, (i64)bm_stride_words, (const i64*)src, \
       (const i64*)dst, (const i64*)order, (i64)B, (i64)n_cols, (const i64*)off, flags, (i64)flags_cap, \
-      (u64*)hist, cnt1, cnt2, status
+      (u64*)hist, cnt1, cnt2, status, (u64*)rec
   if (rowptrT2) {
     if (lh) hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, true, true>), dim3(grid), dim3(OCN_BLOCK), lds, st,
                                CN_FLAGS_ARGS(rowptrT2, colT2));
@@ -1482,13 +1505,13 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream) 
 #define GATHER_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, (const i64*)off, \
                     flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij, (const i64*)out_row
 #define LAUNCH_GATHER(LPE, NV)                                                                      \
-  launch_gather<LPE, NV>(rowptrA, colA, src, dst, order, B, off, flags, wc, weights, h, H, max_row_len, xcn1, xcn2, xij, out_row, cnt1, cnt2, st)
+  launch_gather<LPE, NV>(rowptrA, colA, src, dst, order, B, off, flags, wc, weights, h, H, max_row_len, xcn1, xcn2, xij, out_row, cnt1, cnt2, rec, st)
 
 int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
                   const int64_t* dst, const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
                   const int32_t* wc, const float* weights, const float* h, int32_t H,
                   int64_t max_row_len, float* xcn1, float* xcn2, float* xij, const int64_t* out_row,
-                  const int32_t* cnt1, const int32_t* cnt2, void* stream) {
+                  const int32_t* cnt1, const int32_t* cnt2, const uint64_t* rec, void* stream) {
   if (B < 0 || H <= 0) return OCN_EINVAL;
   if (B == 0) return 0;
   if (!rowptrA || !src || !dst || !off || !weights || !h || !xcn1 || !xcn2 || !xij) return OCN_EINVAL;

@@ -178,10 +178,12 @@ def hist_counts(hist: Tensor) -> Tensor:
 def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
              t2: Optional[Tuple[Tensor, Tensor]], src: Tensor, dst: Tensor, n_cols: int, max_deg_a: int,
              walk: bool = False, t2_bitmap: Optional[Tensor] = None, wsd=None, nds: Optional[Tensor] = None,
-             t1_bitmap: Optional[Tensor] = None):
+             t1_bitmap: Optional[Tensor] = None, rec: Optional[Tensor] = None):
     """Intersection pass.  ``walk=False``: flags of N(src) against the rows of dst in t1 (and t2).
     ``walk=True``: the pygho route on A itself (t1/t2 ignored): cn1 flags + walk counts; with ``nds``
     (``neighbor_degree_sum`` of A) every batch row is swept from its cheaper endpoint.
+    ``rec`` (int64 [B, 4], pattern route): receives the per-slot records ``cn_gather`` reads instead of walking
+    order -> src / dst / off / counts -> rowptr.
     Returns (order|None, off, flags, wc|None, hist[N,2] int64 packed, cnt1, cnt2|None, status, scal) — ``scal``
     is the zeroed int32[4] statistics scratch the weights stage of the same batch uses."""
     dev = src.device
@@ -262,7 +264,7 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
                                       ptr(t1_bitmap), t1_bitmap.shape[1] if t1_bitmap is not None else 0,
                                       ptr(t2_bitmap), t2_bitmap.shape[1] if t2_bitmap is not None else 0,
                                       ptr(src), ptr(dst), ptr(order), B, n_cols, ptr(off), ptr(flags), cap, ptr(hist),
-                                      ptr(cnt1), ptr(cnt2), ptr(status), stream_ptr()), "ocn_cn_flags")
+                                      ptr(cnt1), ptr(cnt2), ptr(status), ptr(rec), stream_ptr()), "ocn_cn_flags")
     _mark("cn_flags")
     return order, off, flags, wc, hist, cnt1, cnt2, status, scal
 
@@ -400,7 +402,7 @@ def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
 @_on_device
 def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights: Tensor, h: Tensor,
               order: Optional[Tensor] = None, max_row_len: int = 0, wsd=None, out_row: Optional[Tensor] = None,
-              cnt1: Optional[Tensor] = None, cnt2: Optional[Tensor] = None):
+              cnt1: Optional[Tensor] = None, cnt2: Optional[Tensor] = None, rec: Optional[Tensor] = None):
     _req(weights, torch.float32, "weights", 2)
     _req(h, torch.float32, "h", 2)
     if weights.shape[0] != h.shape[0] or weights.shape[1] != 4:
@@ -409,7 +411,7 @@ def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights
     out = buf(wsd, "pooled", (3, B, H), torch.float32, h.device)
     check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags),
                                    ptr(wc), ptr(weights), ptr(h), H, int(max_row_len), ptr(out[0]), ptr(out[1]),
-                                   ptr(out[2]), ptr(out_row), ptr(cnt1), ptr(cnt2), stream_ptr()), "ocn_cn_gather")
+                                   ptr(out[2]), ptr(out_row), ptr(cnt1), ptr(cnt2), ptr(rec), stream_ptr()), "ocn_cn_gather")
     _mark("cn_gather")
     return out[0], out[1], out[2]
 
