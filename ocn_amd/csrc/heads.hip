@@ -30,6 +30,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define HD_ROWS 128
 #define HD_KC 2                       /* k-steps per staged panel chunk */
+#ifndef HD_SCHED_VALU
+#define HD_SCHED_VALU 3                   /* VALU / SALU instructions placed behind each MFMA of a k-step */
+#endif
+#ifndef HD_SCHED_SALU
+#define HD_SCHED_SALU 2
+#endif
 #ifndef HD_VMEM_SLOTS
 #define HD_VMEM_SLOTS 20                  /* MFMA gaps of a k-step that may carry an LDS-DMA piece */
 #endif
@@ -123,11 +129,11 @@ struct Heads {
       for (int m = 0; m < 6; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           // one MFMA
         if (m < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // one fragment read of the next tile
-        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);           // VALU
+        __builtin_amdgcn_sched_group_barrier(0x002, HD_SCHED_VALU, 0);   // VALU
         // the LDS-DMA pieces of the next chunk: one behind each of the FIRST MFMAs of the k-step, so that they have the
         // rest of this k-step and all of the next to land before the chunk boundary waits for them
         if (t * 6 + m < HD_VMEM_SLOTS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);           // SALU (M0, addresses)
+        __builtin_amdgcn_sched_group_barrier(0x004, HD_SCHED_SALU, 0);   // SALU (M0, addresses)
       }
     __builtin_amdgcn_sched_barrier(0);
   }

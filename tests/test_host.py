@@ -31,6 +31,37 @@ def test_library_exports_every_declared_symbol(hiplib):
     assert hiplib.ocn_spgemm_max_cols() >= 1_000_000
 
 
+def test_entries_reject_bad_arguments_before_any_launch(hiplib):
+    """Argument errors come back as OCN_EINVAL (-1) from the C entries themselves — checked here without a GPU, since
+    every one of these returns before its first HIP call (ocn_hip.h: error behaviour)."""
+    import ctypes
+    E, NULL = -1, None
+    one = ctypes.c_int64(0)
+    p = ctypes.cast(ctypes.pointer(one), ctypes.c_void_p)          # a non-NULL host pointer: never dereferenced on these paths
+    assert hiplib.ocn_heads_fused(NULL, NULL) == E
+    args = _lib.OcnHeadsArgs()                                     # all-NULL pointers, H = 0
+    assert hiplib.ocn_heads_fused(ctypes.byref(args), NULL) == E
+    assert hiplib.ocn_linear_split_weight_chained(NULL, 256, 256, NULL, NULL) == E
+    assert hiplib.ocn_linear_split_weight_chained(p, 250, 256, p, NULL) == E               # N not a multiple of 32
+    assert hiplib.ocn_cn_colsum_exact(NULL, NULL, NULL, -1, NULL, NULL, NULL, NULL, 0, NULL, 0, NULL, NULL, NULL, NULL, NULL,
+                                      NULL, NULL) == E
+    assert hiplib.ocn_cn_colsum_exact(p, p, p, 4, p, p, NULL, NULL, 1 << 33, p, 4, p, p, NULL, p, NULL, p, NULL) == E   # flags_cap >= 2^32
+    too_many = hiplib.ocn_walk_prep_max_batch() + 1
+    assert hiplib.ocn_walk_prep(p, NULL, p, p, too_many, 2, p, p, p, NULL, p, p, p, p, p, p, p, p, NULL) == E
+    assert hiplib.ocn_dense_from_csr(p, p, 100, 100, p, p, NULL) == E                       # row stride not a multiple of 64
+    assert hiplib.ocn_dense_block_mm_bits(p, p, 128, 128, 8, 40, 0, 32, 0, p, 4, NULL) == E    # block start not a multiple of 32
+    assert hiplib.ocn_bitrows_from_csr(p, p, -1, p, 4, NULL) == E
+    assert hiplib.ocn_bitrows_count(p, 1, 4, 64, p, NULL) == E                              # stride shorter than the columns
+    assert hiplib.ocn_batch_prep(p, p, -1, p, p, 10, NULL, NULL, NULL, 0, NULL) == E
+    assert hiplib.ocn_zero_regions(NULL, NULL, 9, NULL) == E
+    assert hiplib.ocn_check_edges(p, p, -1, 10, 10, p, NULL) == E
+    assert hiplib.ocn_cn_flags(p, p, p, p, NULL, NULL, NULL, 0, NULL, 0, p, p, NULL, -1, 10, p, p, 0, p, p, NULL, p, NULL, NULL) == E
+    assert hiplib.ocn_cn_flags(p, p, NULL, NULL, NULL, NULL, NULL, 0, NULL, 0, p, p, NULL, 4, 10, p, p, 0, p, p, NULL, p, NULL,
+                               NULL) == E                                                    # neither a CSR nor bit rows for T1
+    assert hiplib.ocn_cn_gather(p, p, p, p, NULL, 4, p, p, NULL, p, p, 0, 0, p, p, p, NULL, NULL, NULL, NULL, NULL) == E   # H = 0
+    assert hiplib.ocn_order_by_node_finish(p, 4, 0, p, p, NULL) == E
+
+
 def test_header_cites_reference_lines():
     txt = open(os.path.join(ROOT, "include", "ocn_hip.h")).read()
     for cite in ("utils.py:162-183", "model.py:2261", "model.py:2426-2429", "model.py:42-55",
