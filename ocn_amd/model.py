@@ -6,7 +6,9 @@ CNLinkPredictorbaselearn, model.py:3021-3229), ``convdict`` / ``convdict2`` / ``
 reference's constructor signatures and ``state_dict`` key layout, so checkpoints and the unchanged
 drivers work.  The sparse arithmetic runs in libocn_hip.so (no torch_sparse / pygho / PyG); in eval the
 dense ``Linear`` / ``LayerNorm`` / ``ReLU`` heads run on the bf16x6 MFMA kernel of the same library
-(``_seq_eval`` / ``_heads_grouped``), the ``nn`` modules only hold the parameters (and run under autograd).
+(one fused launch ``ocn_heads_fused`` from H = 128 up, else ``_seq_eval`` / ``_heads_grouped``); under autograd the
+heads' Linear layers run through ``_LinearFn`` (forward and input gradient on the same kernel).  The ``nn`` modules hold
+the parameters.
 """
 from __future__ import annotations
 
@@ -416,6 +418,42 @@ def _seq_eval(seq: nn.Sequential, x: Tensor, y_row_map: Optional[Tensor] = None)
     return x
 
 
+class _LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b with autograd on (training): the forward and the input gradient run on the library's bf16x6
+    MFMA Linear kernel; the weight gradient dY^T @ X (a reduction over the whole batch) and the bias gradient are torch
+    reductions.  The nn.Linear module still owns the parameters (state_dict keys unchanged)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return ops.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.linear_t(gy, weight) if ops.linear_ok_t(gy, weight) else gy @ weight
+        if ctx.needs_input_grad[1]:
+            gw = gy.t() @ x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0)
+        return gx, gw, gb
+
+
+def _seq_train(seq: nn.Sequential, x: Tensor) -> Tensor:
+    """Autograd-mode walk of one of the predictor's heads: every ``nn.Linear`` the MFMA kernel takes runs through
+    ``_LinearFn``; Dropout / LayerNorm / ReLU stay the torch modules (their backward is torch's)."""
+    for m in seq:
+        if isinstance(m, nn.Linear) and x.dim() == 2 and x.is_contiguous() and ops.linear_ok(x, m.weight):
+            x = _LinearFn.apply(x, m.weight, m.bias)
+        else:
+            x = m(x)
+    return x
+
+
 class _CNPredictorBase(nn.Module):
     """Parameters and MLP heads shared by cn5 and cn7 (model.py:2173-2239 ≡ 3023-3089).  The
     ``nn.Sequential`` layouts are part of the checkpoint contract (state_dict keys)."""
@@ -803,10 +841,11 @@ class _CNPredictorBase(nn.Module):
             return self._heads_skipping(xcn1, xcn2, xij, cls)
         if self.training or torch.is_grad_enabled() or not xij.is_cuda or xij.shape[-1] % 4:
             alpha = torch.sigmoid(self.alpha).cumprod(-1)
-            xij = self.xijlin(xij)
-            xcn1 = self.xcn1lin(xcn1)
-            xcn2 = self.xcn2lin(xcn2)
-            return self.lin(alpha[0] * xcn1 + alpha[1] * xcn2 + self.beta * xij)
+            run = _seq_train if (xij.is_cuda and ops.train_linear) else (lambda seq, t: seq(t))
+            xij = run(self.xijlin, xij)
+            xcn1 = run(self.xcn1lin, xcn1)
+            xcn2 = run(self.xcn2lin, xcn2)
+            return run(self.lin, alpha[0] * xcn1 + alpha[1] * xcn2 + self.beta * xij)
         # eval under no_grad (the drivers' test()): same modules, same parameters, on the bf16x6 MFMA
         # Linear kernel with fused LayerNorm/ReLU epilogues.  With autograd on, the torch modules
         # above run instead so that the graph is recorded.

@@ -684,6 +684,7 @@ def linear_panel_chained(weight: Tensor) -> Tensor:
 
 
 HEADS_WIDTHS = (32, 64, 128, 256)
+train_linear = True              # autograd on: the heads' Linear layers (forward and input gradient) on the MFMA kernel
 fused_heads = True               # cn5 / cn7 eval: the whole MLP head as one launch (ocn_heads_fused)
 fused_heads_min_width = 128      # narrower heads (ppa / citation2 / ddi: H = 32..64) have a k-loop of 2-4 steps: the fused
                                  # kernel's per-tile epilogues dominate and the grouped launches are faster (ddi: 18 vs 31 us)
@@ -760,6 +761,28 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, ln=None, re
     check(_lib.lib().ocn_linear_bf16x6(ptr(x), M, K, ptr(panel), N, ptr(bias), ptr(g), ptr(b), float(eps),
                                        int(relu), ptr(dw), ptr(db), ptr(y), stream_ptr()), "ocn_linear_bf16x6")
     _mark("linear", 2.0 * M * K * N)
+    return y
+
+
+def linear_ok_t(gy: Tensor, weight: Tensor) -> bool:
+    """``linear_t`` takes these shapes (the product gy @ weight as a Linear whose weight is weight^T)."""
+    return (fast_linear and gy.is_cuda and gy.dim() == 2 and gy.dtype == torch.float32
+            and weight.shape[1] in LINEAR_WIDTHS and weight.shape[0] % 16 == 0 and weight.shape[0] == gy.shape[1])
+
+
+@_on_device
+def linear_t(gy: Tensor, weight: Tensor) -> Tensor:
+    """gy @ weight ([M, N] x [N, K] -> [M, K]) on the bf16x6 MFMA kernel: the input gradient of y = x @ weight^T.
+    The transposed panel is built per call (the weight changes with every optimiser step)."""
+    gy = _req(gy.contiguous(), torch.float32, "gy", 2)
+    wt = _req(weight.detach().t().contiguous(), torch.float32, "weight^T", 2)          # [K, N]: K outputs, N inputs
+    K, N = wt.shape
+    M = gy.shape[0]
+    panel = torch.empty(int(_lib.lib().ocn_linear_panel_bytes(K, N)), dtype=torch.uint8, device=wt.device)
+    check(_lib.lib().ocn_linear_split_weight(ptr(wt), K, N, ptr(panel), stream_ptr()), "ocn_linear_split_weight")
+    y = torch.empty((M, K), dtype=torch.float32, device=gy.device)
+    check(_lib.lib().ocn_linear_bf16x6(ptr(gy), M, N, ptr(panel), K, None, None, None, 0.0, 0, None, None, ptr(y),
+                                       stream_ptr()), "ocn_linear_bf16x6")
     return y
 
 

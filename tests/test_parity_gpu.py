@@ -164,6 +164,36 @@ def test_backward_matches_oracle_autograd(case, name):
         assert (p.grad.cpu() - g).abs().max().item() <= 2e-5 * max(1.0, g.abs().max().item()), k
 
 
+def test_heads_under_autograd_run_on_the_library_linear(case, monkeypatch):
+    """With autograd on, the heads' Linear layers (forward and input gradient) go through ocn_linear_bf16x6
+    (model._LinearFn); switching that off (torch modules) gives the same scores and gradients to rounding."""
+    from ocn_amd import ops
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    H = 64
+    torch.manual_seed(case.seed + 5)
+    x = torch.randn(case.n, H, device=DEV)
+    pred = predictor_dict["cn5"](H, H, 1, 3, 0.0, 0.0, True).to(DEV).eval()
+    e = case.e.to(DEV)
+    calls = {"fwd": 0, "bwd": 0}
+    lin, lin_t = ops.linear, ops.linear_t
+    monkeypatch.setattr(ops, "linear", lambda *a, **k: (calls.__setitem__("fwd", calls["fwd"] + 1), lin(*a, **k))[1])
+    monkeypatch.setattr(ops, "linear_t", lambda *a, **k: (calls.__setitem__("bwd", calls["bwd"] + 1), lin_t(*a, **k))[1])
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ops, "train_linear", on)
+        xd = x.clone().requires_grad_(True)
+        pred.zero_grad(set_to_none=True)
+        out = pred(xd, case.adj, adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e), e, None)
+        out.square().sum().backward()
+        res[on] = (out.detach(), xd.grad, {k: p.grad.clone() for k, p in pred.named_parameters() if p.grad is not None})
+        if on:
+            assert calls["fwd"] >= 9 and calls["bwd"] >= 9                   # 9 Linear(H, H) of the head, each way
+    assert close(res[True][0], res[False][0])
+    for a, b in [(res[True][1], res[False][1])] + [(res[True][2][k], res[False][2][k]) for k in res[False][2]]:
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+
+
 def test_training_mode_updates_running_innerprod(case):
     from ocn_amd.model import predictor_dict
     from ocn_amd.utils import adjoverlap
