@@ -273,7 +273,13 @@ def cpu_baseline(wl, args, mine):
     torch.set_num_threads(best)
     t, out = run(full)
     builder = "get_cn1_cn2" if oadj2 is None else "adjoverlap x2"
-    return dict(value=full / t, unit="edges/s", cores=best, kind="port",
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return dict(value=full / t, unit="edges/s", cores=best, kind="port", cpu_model=model, usable_cores=ncores,
                 sample=f"the step's {'full ' if full == mine.shape[1] else ''}{full}-edge batch as one batch, "
                        f"oracle/ocn_oracle.py {builder} + {cfg['pred']}_forward (rowptr cached), {t:.2f} s with {best} torch "
                        f"threads of {ncores} usable cores; thread sweep on {probe} edges: "
