@@ -994,7 +994,10 @@ __device__ __forceinline__ void long_store(const f32x4 (&x)[RPG][NV], float4* __
 // entry and accumulator, not a float4's worth of them on a quarter of the lanes.
 // LONG_THREADS: 1024 for small batches (few hub rows, each as parallel as a workgroup gets), 256 for large ones (one
 // workgroup is launched per batch row and all but the hub rows' leave at once).
-#define LONG_SLAB_BYTES(threads) ((threads) >= 1024 ? 32768 : 16384)   /* per half; dynamic LDS = two halves */
+#ifndef LONG_SMALL_THREADS
+#define LONG_SMALL_THREADS 1024             /* hub-row workgroup of a small batch (B <= 4096); 512 (two per CU) measured 5 % slower */
+#endif
+#define LONG_SLAB_BYTES(threads) ((threads) >= 512 ? 32768 : 16384)   /* per half; dynamic LDS = two halves */
 template <int LPE, int NV, int LONG_THREADS>
 __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
@@ -1350,10 +1353,10 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
       static bool raised_dev[64] = {};        // 2 x 64 KiB of slab: above the default dynamic-LDS limit (attribute is per device)
       int devid = 0;
       if (hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < 64 && !raised_dev[devid]) {
-        if (hipFuncSetAttribute((const void*)cn_gather_long_kernel<LPE, NV, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * LONG_SLAB_BYTES(1024)) == hipSuccess) raised_dev[devid] = true;
+        if (hipFuncSetAttribute((const void*)cn_gather_long_kernel<LPE, NV, LONG_SMALL_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * LONG_SLAB_BYTES(LONG_SMALL_THREADS)) == hipSuccess) raised_dev[devid] = true;
       }
-      hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV, 1024>), dim3((unsigned)B), dim3(1024), 2 * LONG_SLAB_BYTES(1024), st, LONG_ARGS);
+      hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV, LONG_SMALL_THREADS>), dim3((unsigned)B), dim3(LONG_SMALL_THREADS), 2 * LONG_SLAB_BYTES(LONG_SMALL_THREADS), st, LONG_ARGS);
     }
     else {
       bool by_wave = false;
