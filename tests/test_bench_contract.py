@@ -22,7 +22,11 @@ def test_committed_bench_line_has_the_contract_keys():
     assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] <= 1.0 and "traffic" in r
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["frac"] > 0 and "traffic" in r
+    if r["bound"] == "hbm":
+        assert r["frac"] <= 1.0
+    else:                                                       # f32 work on the bf16 pipe may pass the f32 MFMA peak; the pipe it runs on may not
+        assert 0 < r["executed_frac_of_bf16_peak"] <= 1.0 and r["frac"] < 6.0
     for rr in d.get("rooflines", {}).values():                  # every per-kernel object: an achieved rate never above its peak
         assert 0 < rr["frac"] <= 1.0 and (rr.get("traffic_frac") is None or rr["traffic_frac"] <= 1.0)
     c = d["cpu_baseline"]
