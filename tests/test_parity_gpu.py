@@ -928,6 +928,38 @@ def test_bitmap_and_csr_search_of_adj_agree(case, monkeypatch):
     assert b.cnt1.cpu().tolist() == torch.bincount(case.ocn1.row, minlength=case.B).tolist()
 
 
+@pytest.mark.parametrize("ip", [0.0, 0.37])
+def test_integration_md_ctypes_stub_runs_as_written(case, ip):
+    """The ctypes stub of INTEGRATION.md §3 (what a maintainer would write against include/ocn_hip.h), executed
+    verbatim: same counts and bit-identical pooled vectors as the library's own Python host."""
+    import re
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import CNState
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = re.search(r"One candidate batch, cn5:\n\n```python\n(.*?)```", open(os.path.join(root, "INTEGRATION.md")).read(), re.S).group(1)
+    H = 64
+    torch.manual_seed(9)
+    h = torch.randn(case.n, H, device=DEV)
+    predictor = predictor_dict["cn5"](H, H, 1, 3, 0.0).to(DEV).eval()
+    with torch.no_grad():
+        predictor.innerprod.fill_(ip)
+    e = case.e.to(DEV)
+    env = dict(dev=DEV, B=case.B, N=case.n, H=H, max_deg=max(case.adj.max_rowcount(), 1), h=h, predictor=predictor,
+               rowptrA=case.adj._rowptr, colA=case.adj._col, rowptrA2=case.adj2._rowptr, colA2=case.adj2._col,
+               bitrowsA2=case.adj2._bitmap, src=e[0].contiguous(), dst=e[1].contiguous())
+    cwd = os.getcwd()
+    os.chdir(root)                                        # the stub opens "ocn_amd/libocn_hip.so"
+    try:
+        exec(compile(code, "INTEGRATION.md", "exec"), env)
+    finally:
+        os.chdir(cwd)
+    torch.cuda.synchronize()
+    st = CNState(case.adj, case.adj, case.adj2, e)
+    assert torch.equal(env["cnt1"], st.cnt1) and torch.equal(env["cnt2"], st.cnt2)
+    x1, x2, xij = st.gather(st.weights_cn5(predictor.innerprod), h)
+    assert torch.equal(env["out"][0], x1) and torch.equal(env["out"][1], x2) and torch.equal(env["out"][2], xij)
+
+
 def test_eval_caches_follow_parameter_updates(case):
     """The eval fast path caches weight panels and mix coefficients; optimiser-style in-place updates
     (version bump) and .data edits followed by a mode switch must both be seen."""
