@@ -414,6 +414,37 @@ def test_hub_rows_longer_than_a_wave(hiplib):
             assert torch.equal(p1.cpu(), q1) and torch.equal(p2.cpu(), q2)
 
 
+@pytest.mark.parametrize("H", [32, 64, 128, 256])
+def test_hub_rows_in_a_large_batch(hiplib, H):
+    """Batches above 4096 rows take other hub-row kernels than the small ones: one wave per hub row for narrow
+    embeddings (the ddi shape), a 256-thread workgroup for wide ones.  Two hubs (1500 and 2500 neighbours) among
+    5000 candidates: the pooled vectors of every row equal the oracle's, bit for bit."""
+    from ocn_amd.utils import CNState
+    n, B = 4000, 5000
+    g = torch.Generator().manual_seed(H)
+    star_a = torch.stack([torch.zeros(2500, dtype=torch.long), torch.arange(2, 2502)])
+    star_b = torch.stack([torch.ones(1500, dtype=torch.long), torch.arange(2400, 3900)])
+    rnd = torch.randint(2, n, (2, 6000), generator=g)
+    oadj = O.to_symmetric(O.from_edge_index(torch.cat([star_a, star_b, rnd], 1), n))
+    oadj2 = O.adj2_sparse(oadj)
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    e = torch.randint(0, n, (2, B), generator=g)
+    e[0, ::7] = 0                                           # hub sources, spread over the batch
+    e[0, 3::11] = 1
+    st = CNState(adj, adj, adj2, e.to(DEV))
+    assert int(adj.storage.rowcount()[:2].min()) > 1024 and st.B > 4096
+    c1, c2 = O.adjoverlap(oadj, oadj, e), O.adjoverlap(oadj, oadj2, e)
+    assert st.cnt1.cpu().tolist() == torch.bincount(c1.row, minlength=B).tolist()
+    x = torch.randn(n, H, generator=g)
+    for ip in (0.0, 0.45):
+        r1, r2, _ = O.cn5_pool(x, c1, c2, torch.tensor([ip]))
+        st = CNState(adj, adj, adj2, e.to(DEV))
+        g1, g2, gx = st.gather(st.weights_cn5(torch.tensor([ip], device=DEV)), x.to(DEV))
+        assert torch.equal(g1.cpu(), r1) and torch.equal(g2.cpu(), r2)
+        assert torch.equal(gx.cpu(), x[e[0]] * x[e[1]])
+
+
 # ---- encoders -----------------------------------------------------------------------------
 ENC = [  # cls, conv_fn, layers, in, hid, ln, res, jk, max_x
     ("GCN", "puregcn", 1, 40, 64, False, False, True, -1),
