@@ -405,7 +405,7 @@ def test_hub_rows_longer_than_a_wave(hiplib):
     # them in ascending column order — the reference's sequential sum, bit for bit, like every short row
     assert int(adj.storage.rowcount()[0]) > 1024
     assert torch.equal(g2.cpu(), r2)
-    for H in (32, 64):                        # other lane-group widths of the hub-row kernel
+    for H in (32, 64, 128, 512):              # other lane-group widths of the hub-row kernel
         xh = torch.randn(n, H, generator=torch.Generator().manual_seed(H))
         for ip in (0.0, 0.6):
             q1, q2, _ = O.cn5_pool(xh, c1, c2, torch.tensor([ip]))
@@ -414,7 +414,7 @@ def test_hub_rows_longer_than_a_wave(hiplib):
             assert torch.equal(p1.cpu(), q1) and torch.equal(p2.cpu(), q2)
 
 
-@pytest.mark.parametrize("H", [32, 64, 128, 256])
+@pytest.mark.parametrize("H", [32, 64, 128, 256, 512])
 def test_hub_rows_in_a_large_batch(hiplib, H):
     """Batches above 4096 rows take other hub-row kernels than the small ones: one wave per hub row for narrow
     embeddings (the ddi shape), a 256-thread workgroup for wide ones.  Two hubs (1500 and 2500 neighbours) among
