@@ -364,14 +364,32 @@ def main():
     pred.set_edge_sharding(None, enabled=world > 1 or args.rehearse_collectives)
 
     pending = [None]                               # the previous batch's score all-gather (N > 1), still in flight
+    kept = None                                    # per-rank scores of the timed loop's batches (N > 1), gathered once at its end
+    # N > 1: two batches in flight — the intersection pass of batch t + 1 is enqueued before batch t waits for its
+    # histogram all-reduce (predictor.begin / .finish), so the collective runs beside compute instead of stalling the
+    # stream.  The timed loop still begins and finishes exactly K batches between its barriers.
+    pipelined = (world > 1 or args.rehearse_collectives) and not args.graph
+    ahead = [None, -1]                             # [token of the batch already begun, its index]
 
-    def step(it=0):
+    def begin(it):
+        mine = mines[it % NB]
+        c1, c2 = cn_handles(wl, mine)
+        return pred.begin(h, adj, c1, c2, mine, slot=it)
+
+    def step(it=0, last=True):
         with torch.no_grad():
             mine = mines[it % NB]
-            c1, c2 = cn_handles(wl, mine)
-            loc = pred(h, adj, c1, c2, mine, wl["args"])
-            # the scores are consumed after the loop: the all-gather of batch t runs beside batch t + 1 (its own
-            # stream); every one of them has completed when the closing synchronize returns
+            if pipelined:
+                tok = ahead[0] if ahead[1] == it else begin(it)
+                ahead[0], ahead[1] = (None, -1) if last else (begin(it + 1), it + 1)
+                loc = pred.finish(h, tok, wl["args"])
+            else:
+                c1, c2 = cn_handles(wl, mine)
+                loc = pred(h, adj, c1, c2, mine, wl["args"])
+            if pipelined and kept is not None:     # timed loop, N > 1: a scoring loop consumes its scores at the end —
+                kept.append(loc)                   # every rank keeps its slices and ONE all-gather closes the loop
+                return loc
+            # otherwise gather per batch; the all-gather of batch t runs beside batch t + 1 (its own stream)
             if pending[0] is not None:
                 pending[0].wait()
             out, pending[0] = gather_scores(loc, B_total, async_op=True)
@@ -389,7 +407,7 @@ def main():
                                route="walk" if cfg["route"] == "walk" else "pattern")
         eager_step = step
 
-        def step(it=0):
+        def step(it=0, last=True):
             return scorer(mines[it % NB])
         for b in range(NB):
             assert torch.equal(step(b), eager_step(b))
@@ -423,6 +441,8 @@ def main():
         t0 = time.perf_counter()
         t_wait = 0.0
         out = None
+        nonlocal kept
+        kept = [] if pipelined else None
         for it in range(steps):
             tw = time.perf_counter()
             ring[it % run_ahead].synchronize()
@@ -430,7 +450,7 @@ def main():
             if timer:                                  # stage events on every `timer_every`-th step only: on a busy
                 timer.active = it % args.timer_every == 0   # host each hipEventRecord costs tens of microseconds
                 timer.mark("begin")
-            out = step(it)
+            out = step(it, last=(it == steps - 1))
             if timer:
                 timer.mark("mlp_glue")
             ring[it % run_ahead].record()
@@ -438,11 +458,16 @@ def main():
         if pending[0] is not None:
             pending[0].wait()
             pending[0] = None
+        if kept:                                        # the loop's one score all-gather, inside the timed region
+            allsc = gather_scores(torch.cat(kept, 0), len(kept) * B_total)
+            per = kept[0].shape[0]
+            out = allsc.view(world, len(kept), per, -1)[:, -1].reshape(world * per, -1)     # the last batch, in batch order
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        kept = None
         ops.stage_timer = None
         if world > 1:
             tmax = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -515,6 +515,38 @@ class _CNPredictorBase(nn.Module):
             ops._mark("allreduce_hist")
         return st
 
+    # ---- two-phase scoring (eval, no grad) for loops that keep two batches in flight ---------------------------
+    # begin(t + 1) is enqueued before finish(t): in the edge-sharded mode the histogram all-reduce of batch t then
+    # runs beside the intersection pass of batch t + 1 instead of stalling the stream (ocn_amd/dist.py; bench.py).
+    def begin(self, x, adj, cn1, cn2, tar_ei, slot: int = 0):
+        """Phase A: the intersection pass of one batch (scratch set ``slot`` & 1 — a batch in phase A must not share
+        buffers with the one still in phase B) and, sharded, the START of the histogram sum.  Returns a token."""
+        if self.training or torch.is_grad_enabled():
+            raise RuntimeError("begin / finish is the no-grad scoring path: call .eval() under torch.no_grad()")
+        if not hasattr(self, "_ws_slots"):
+            self._ws_slots = [dict(), dict()]
+        st = fuse(cn1, cn2, tar_ei, self._ws_slots[slot & 1], adj=adj)
+        handle = None
+        if self._sharded:
+            from .dist import allreduce_hist_start
+            # the whole interleaved buffer, no copy-out / copy-back of the packed word: the collective is hidden behind the
+            # next batch's intersection pass, its extra bytes are free, the two copies were not
+            handle = allreduce_hist_start(st.hist, self._shard_group, valued=True)
+            st.sharded, st.shard_group = True, self._shard_group
+        return st, handle
+
+    def finish(self, x, token, args=None):
+        """Phase B: class order (beside the collective), wait for the histogram sum, weights, pooling, heads."""
+        st, handle = token
+        self._class_order(st, x)
+        if handle is not None:
+            from .dist import allreduce_hist_finish
+            allreduce_hist_finish(handle)
+            ops._mark("allreduce_hist")
+        w = self._weights(st, args)
+        xcn1, xcn2, xij = self._pool(st, w, x)
+        return self._heads(x, xcn1, xcn2, xij, getattr(st, "cls", None))
+
     def _class_order(self, st, x) -> None:
         """Class-major rows (candidates without cn1 / cn2 entries end up in contiguous ranges the heads skip) where
         that pays; sets ``st.cls`` (None = batch order)."""
@@ -866,9 +898,12 @@ class CNLinkPredictorOringin(_CNPredictorBase):
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
         st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x), adj=adj), x)
-        w = st.weights_cn5(self.innerprod1(st))
+        w = self._weights(st, None)
         xcn1, xcn2, xij = self._pool(st, w, x)
         return self._heads(x, xcn1, xcn2, xij, getattr(st, "cls", None))
+
+    def _weights(self, st, args):
+        return st.weights_cn5(self.innerprod1(st))
 
     def forward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False):
         return self.multidomainforward(x, adj, cn1, cn2, tar_ei, filled1, [])
@@ -882,9 +917,12 @@ class CNLinkPredictorbaselearn(_CNPredictorBase):
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, args, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
         st = self._exchange(fuse(cn1, cn2, tar_ei, self._scratch(x), adj=adj), x)
-        w = st.weights_cn7(float(args.sum))
+        w = self._weights(st, args)
         xcn1, xcn2, xij = self._pool(st, w, x)
         return self._heads(x, xcn1, xcn2, xij, getattr(st, "cls", None))
+
+    def _weights(self, st, args):
+        return st.weights_cn7(float(args.sum))
 
     def forward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False):
         # the drivers pass the argparse Namespace in this slot (NeighborOverlap_large.py:122)

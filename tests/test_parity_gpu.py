@@ -991,6 +991,36 @@ def test_integration_md_ctypes_stub_runs_as_written(case, ip):
     assert torch.equal(env["out"][0], x1) and torch.equal(env["out"][1], x2) and torch.equal(env["out"][2], xij)
 
 
+@pytest.mark.parametrize("name", ["cn5", "cn7"])
+def test_two_phase_scoring_keeps_two_batches_in_flight(case, name):
+    """predictor.begin / .finish (the pipelined loop of the sharded bench): the intersection pass of batch t + 1 is
+    enqueued before batch t is finished, on alternating scratch sets — every batch scores exactly as forward() does."""
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    H = 64
+    torch.manual_seed(case.seed + 3)
+    x = torch.randn(case.n, H, device=DEV)
+    pred = predictor_dict[name](H, H, 1, 3, 0.0, 0.0, True).to(DEV).eval()
+    args = SimpleNamespace(sum=0.7)
+    g = torch.Generator().manual_seed(4)
+    batches = [case.e.to(DEV)[:, torch.randperm(case.B, generator=g).to(DEV)][:, : max(case.B - 3 * q, 1)].contiguous() for q in range(4)]
+
+    def handles(e):
+        return adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e)
+
+    with torch.no_grad():
+        ref = [pred(x, case.adj, *handles(e), e, args).clone() for e in batches]
+        outs, tok = [], pred.begin(x, case.adj, *handles(batches[0]), batches[0], slot=0)
+        for t in range(len(batches)):
+            nxt = pred.begin(x, case.adj, *handles(batches[t + 1]), batches[t + 1], slot=t + 1) if t + 1 < len(batches) else None
+            outs.append(pred.finish(x, tok, args).clone())
+            tok = nxt
+    for a, b in zip(outs, ref):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        pred.begin(x, case.adj, *handles(batches[0]), batches[0])         # autograd on: not the scoring path
+
+
 def test_eval_caches_follow_parameter_updates(case):
     """The eval fast path caches weight panels and mix coefficients; optimiser-style in-place updates
     (version bump) and .data edits followed by a mode switch must both be seen."""
