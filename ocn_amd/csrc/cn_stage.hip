@@ -614,7 +614,9 @@ __device__ __forceinline__ void entry_weights(unsigned f, const float4& w, float
 #ifndef OCN_X_GATHER_UNR
 #define OCN_X_GATHER_UNR 4
 #endif
-template <int LPE, int NV, int UNR = OCN_X_GATHER_UNR>
+// (eight for the one-wave-per-candidate layout of H >= 256 — one candidate's gathers are all a wave has in flight:
+// 0.214 -> 0.206 ms at the collab shape; four where several candidates share a wave)
+template <int LPE, int NV, int UNR = (LPE >= 64 ? 2 * OCN_X_GATHER_UNR : OCN_X_GATHER_UNR)>
 __device__ __forceinline__ void pool_range(i64 p_begin, i64 p_end, i64 a0, i64 base, int gl, int gbase,
                                            const int32_t* __restrict__ colA, const uint8_t* __restrict__ flags,
                                            const int32_t* __restrict__ wc, const float4* __restrict__ weights,
