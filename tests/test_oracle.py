@@ -201,3 +201,30 @@ def test_oracle_reproduces_its_committed_vectors():
         assert adj3.nnz == rec["a3_nnz"] and torch.bincount(cn3.row, minlength=e.shape[1]).tolist() == rec["cn3_counts"]
         c = O.cn6_pool(x, cn1, cn2, cn3, torch.tensor([0.37]))[2]
         assert c[0].tolist() == rec["cn6_ip0.37"]["xcn3_row0"]
+
+
+def test_order_sensitive_column_sum_known_answer():
+    """A column whose fp32 sum depends on the order of its five entries (tests/golden/order_sensitive_colsum.json, derived
+    by hand): the reference's index_add_ adds them in ascending batch-row order -> 2^25 exactly; adding the small
+    entries first, or rounding the exact sum once, gives 2^25 + 4."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "order_sensitive_colsum.json")))
+    adj = O.to_symmetric(O.from_edge_index(torch.tensor(g["undirected_edges"]).t(), g["n"]))
+    a2 = O.adj2_sparse(adj)
+    e = torch.tensor(g["batch"]).t().contiguous()
+    cn1, cn2 = O.adjoverlap(adj, adj, e), O.adjoverlap(adj, a2, e)
+    k = g["column"]
+    assert cn1.row.tolist() == [0, 4] and cn1.col.tolist() == [k, k]
+    assert cn2.row.tolist() == [1, 2, 3] and cn2.col.tolist() == [k, k, k]
+    _, _, aux = O.cn5_pool(torch.randn(g["n"], 4), cn1, cn2, torch.tensor([g["innerprod"]]))
+    assert aux["scale"] == 0.5 and aux["nip"] == -2.0 ** 25
+    v = aux["ncn2"].val * aux["S2"][k]                                   # the union values, in batch-row order
+    assert v.tolist() == g["values_in_batch_row_order"]
+    assert aux["S2"][k].item() == g["S2_reference_order"]
+    ones_first = torch.tensor([1.0, 1.0, 1.0, 2.0 ** 24, 2.0 ** 24])
+    acc = torch.tensor(0.0)
+    for t in ones_first:
+        acc = acc + t
+    assert acc.item() == g["S2_ones_first_or_rounded_once"] != g["S2_reference_order"]
+    assert float(torch.tensor(sum(g["values_in_batch_row_order"]), dtype=torch.float64).float()) == g["S2_ones_first_or_rounded_once"]

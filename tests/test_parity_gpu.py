@@ -1021,6 +1021,27 @@ def test_two_phase_scoring_keeps_two_batches_in_flight(case, name):
         pred.begin(x, case.adj, *handles(batches[0]), batches[0])         # autograd on: not the scoring path
 
 
+def test_order_sensitive_column_sum_known_answer_on_the_gpu(hiplib):
+    """tests/golden/order_sensitive_colsum.json (hand-derived): five entries in one column whose fp32 sum is 2^25 only in
+    ascending batch-row order (2^25 + 4 with the small entries first, or with one rounding of the exact sum)."""
+    from ocn_amd.utils import CNState
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "order_sensitive_colsum.json")))
+    oadj = O.to_symmetric(O.from_edge_index(torch.tensor(g["undirected_edges"]).t(), g["n"]))
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    e = torch.tensor(g["batch"]).t().contiguous()
+    k = g["column"]
+    ip = torch.tensor([g["innerprod"]], device=DEV)
+    st = CNState(adj, adj, adj2, e.to(DEV))
+    assert st.cnt1.cpu().tolist() == [1, 0, 0, 0, 1] and st.cnt2.cpu().tolist() == [0, 1, 1, 1, 0]
+    w = st.weights_cn5(ip)
+    assert w[k, 2].item() == 1.0 / g["S2_reference_order"] != 1.0 / g["S2_ones_first_or_rounded_once"]
+    x = torch.randn(g["n"], 32, generator=torch.Generator().manual_seed(2))
+    r1, r2, _ = O.cn5_pool(x, O.adjoverlap(oadj, oadj, e), O.adjoverlap(oadj, O.adj2_sparse(oadj), e), ip.cpu())
+    g1, g2, _ = st.gather(w, x.to(DEV))
+    assert torch.equal(g1.cpu(), r1) and torch.equal(g2.cpu(), r2)
+
+
 def test_eval_caches_follow_parameter_updates(case):
     """The eval fast path caches weight panels and mix coefficients; optimiser-style in-place updates
     (version bump) and .data edits followed by a mode switch must both be seen."""
