@@ -228,3 +228,25 @@ def test_order_sensitive_column_sum_known_answer():
         acc = acc + t
     assert acc.item() == g["S2_ones_first_or_rounded_once"] != g["S2_reference_order"]
     assert float(torch.tensor(sum(g["values_in_batch_row_order"]), dtype=torch.float64).float()) == g["S2_ones_first_or_rounded_once"]
+
+
+def test_order_sensitive_pooling_known_answer():
+    """tests/golden/order_sensitive_pooling.json (hand-derived): a pooled value that is 2^23 only when a row's entries are
+    added in ascending column order, 2^23 + 2 in descending order."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "order_sensitive_pooling.json")))
+    adj = O.to_symmetric(O.from_edge_index(torch.tensor(g["undirected_edges"]).t(), g["n"]))
+    e = torch.tensor(g["batch"]).t().contiguous()
+    cn1, cn2 = O.adjoverlap(adj, adj, e), O.adjoverlap(adj, O.adj2_sparse(adj), e)
+    assert cn1.col.tolist() == [2, 3, 4, 5, 2, 3, 4, 5]
+    x = torch.zeros(g["n"], 4)
+    for k, v in g["x_rows"].items():
+        x[int(k)] = v
+    xcn1, _, aux = O.cn5_pool(x, cn1, cn2, torch.tensor([0.0]))
+    assert aux["inv1"][2:6].tolist() == [0.5] * 4
+    assert xcn1.unique().tolist() == [g["xcn1_ascending_column_order"]]
+    acc = torch.tensor(0.0)
+    for v in (1.0, 1.0, 1.0, 2.0 ** 24):
+        acc = acc + torch.tensor(0.5) * v
+    assert acc.item() == g["xcn1_descending_column_order"]

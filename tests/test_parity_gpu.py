@@ -1042,6 +1042,24 @@ def test_order_sensitive_column_sum_known_answer_on_the_gpu(hiplib):
     assert torch.equal(g1.cpu(), r1) and torch.equal(g2.cpu(), r2)
 
 
+@pytest.mark.parametrize("H", [16, 64, 256, 48])
+def test_order_sensitive_pooling_known_answer_on_the_gpu(hiplib, H):
+    """tests/golden/order_sensitive_pooling.json (hand-derived): 2^23 only in ascending column order — every pooling kernel
+    layout (lane groups of 4 / 16 / 64 lanes, the generic width)."""
+    from ocn_amd.utils import CNState
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "order_sensitive_pooling.json")))
+    oadj = O.to_symmetric(O.from_edge_index(torch.tensor(g["undirected_edges"]).t(), g["n"]))
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    e = torch.tensor(g["batch"]).t().contiguous().to(DEV)
+    x = torch.zeros(g["n"], H, device=DEV)
+    for k, v in g["x_rows"].items():
+        x[int(k)] = v
+    for st in (CNState(adj, adj, adj2, e), CNState(adj, None, None, e, walk=True)):
+        x1, _, _ = st.gather(st.weights_cn5(torch.zeros(1, device=DEV)), x)
+        assert x1.unique().tolist() == [g["xcn1_ascending_column_order"]]
+
+
 def test_eval_caches_follow_parameter_updates(case):
     """The eval fast path caches weight panels and mix coefficients; optimiser-style in-place updates
     (version bump) and .data edits followed by a mode switch must both be seen."""
