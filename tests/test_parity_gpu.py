@@ -1060,6 +1060,32 @@ def test_order_sensitive_pooling_known_answer_on_the_gpu(hiplib, H):
         assert x1.unique().tolist() == [g["xcn1_ascending_column_order"]]
 
 
+@pytest.mark.parametrize("H,B", [(32, 2), (64, 2), (256, 2), (64, 5000), (256, 5000)])
+def test_order_sensitive_pooling_of_a_hub_row(hiplib, H, B):
+    """The hub-row kernels against a hand-derived value: source 0 and target 1 share 1500 neighbours (2..1501), the pair
+    is scored twice (weight 1/2 per column), x[2] = 2^24 and x[k] = 1 elsewhere.  Added in ascending column order the
+    pooled value is 2^23 — each later 0.5 is absorbed (ties to even); ANY order that adds some of the small terms
+    together first (segments, partial sums per lane group) ends above it.  B = 2: workgroup kernel of small batches;
+    B = 5000: one wave per hub row (H <= 64) / the 256-thread workgroup kernel."""
+    from ocn_amd.utils import CNState
+    n, m = 1502, 1500
+    nb = torch.arange(2, 2 + m)
+    ei = torch.cat([torch.stack([torch.zeros(m, dtype=torch.long), nb]), torch.stack([torch.ones(m, dtype=torch.long), nb])], 1)
+    oadj = O.to_symmetric(O.from_edge_index(ei, n))
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    e = torch.tensor([[0, 0], [1, 1]])
+    if B > 2:                                               # filler candidates (2, 3): their entries are in columns 0 and 1 only
+        e = torch.cat([e, torch.tensor([[2], [3]]).expand(2, B - 2)], 1)
+    e = e.contiguous().to(DEV)
+    x = torch.ones(n, H, device=DEV)
+    x[2] = 2.0 ** 24
+    st = CNState(adj, adj, adj2, e)
+    assert int(adj.storage.rowcount()[0]) == m > 1024 and st.cnt1[:2].cpu().tolist() == [m, m]
+    x1, _, _ = st.gather(st.weights_cn5(torch.zeros(1, device=DEV)), x)
+    assert x1[:2].unique().tolist() == [2.0 ** 23]
+
+
 def test_eval_caches_follow_parameter_updates(case):
     """The eval fast path caches weight panels and mix coefficients; optimiser-style in-place updates
     (version bump) and .data edits followed by a mode switch must both be seen."""
