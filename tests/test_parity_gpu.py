@@ -1086,6 +1086,26 @@ def test_order_sensitive_pooling_of_a_hub_row(hiplib, H, B):
     assert x1[:2].unique().tolist() == [2.0 ** 23]
 
 
+@pytest.mark.parametrize("F", [16, 64, 128, 256])
+def test_order_sensitive_spmm_known_answer(hiplib, F):
+    """The encoders' SpMM (spmm_add of model.py:42-55) against hand-derived values: row 0 has the neighbours 1 < 2 < 3 < 4 with
+    x[1] = 2^24 and x[2..4] = 1.  Ascending column order: 2^24 + 1 = 2^24 three times -> 2^24 (descending: 3 + 2^24 ->
+    2^24 + 4).  With the self term of PureConv added AFTER the neighbours (y = A x + x, x[0] = 1): still 2^24."""
+    from ocn_amd import ops
+    rowptr = torch.tensor([0, 4, 4, 4, 4, 4], dtype=torch.int64, device=DEV)
+    col = torch.tensor([1, 2, 3, 4], dtype=torch.int32, device=DEV)
+    x = torch.ones(5, F, device=DEV)
+    x[1] = 2.0 ** 24
+    y = ops.spmm_csr(rowptr, col, x)
+    assert y[0].unique().tolist() == [2.0 ** 24] and y[1:].abs().max().item() == 0.0
+    y = ops.spmm_csr(rowptr, col, x, self_mode=1)                       # neighbours first, then the row's own x
+    assert y[0].unique().tolist() == [2.0 ** 24]
+    acc = torch.tensor(0.0)
+    for v in (1.0, 1.0, 1.0, 2.0 ** 24):                                # what a descending sum would give
+        acc = acc + v
+    assert acc.item() == 2.0 ** 24 + 4
+
+
 def test_eval_caches_follow_parameter_updates(case):
     """The eval fast path caches weight panels and mix coefficients; optimiser-style in-place updates
     (version bump) and .data edits followed by a mode switch must both be seen."""
