@@ -163,7 +163,8 @@ def adj2_by_block(adj: SpM, block_size: int = 1024, fold_quirk: bool = False) ->
     ``fold_quirk=True``: reproduces SURVEY.md Q7 — ``SparseTensor.from_dense``
     yields block-local indices that the reference adds without an offset, so all
     tiles fold onto the top-left corner ([3P-memory]: depends on torch_sparse's
-    SparseTensor + SparseTensor; documented, never asserted against the GPU)."""
+    SparseTensor + SparseTensor).  Both readings are pinned by hand-derived path-graph
+    answers (tests/test_oracle.py) and asserted against the product's block route."""
     n = adj.n_rows
     dense = adj.to_dense()
     rows, cols, vals = [], [], []

@@ -250,3 +250,27 @@ def test_order_sensitive_pooling_known_answer():
     for v in (1.0, 1.0, 1.0, 2.0 ** 24):
         acc = acc + torch.tensor(0.5) * v
     assert acc.item() == g["xcn1_descending_column_order"]
+
+
+def _path_adj2_patterns(n, bs):
+    """A^2 of the path 0-1-...-(n-1), derived by hand: (i, i) for every i (degree >= 1) and (i, i +- 2).  Folded by blocks
+    of `bs` (block-local indices added without the block offset): every entry (i, j) lands on (i % bs, j % bs)."""
+    full = {(i, i) for i in range(n)} | {(i, i + 2) for i in range(n - 2)} | {(i + 2, i) for i in range(n - 2)}
+    return full, {(i % bs, j % bs) for i, j in full}
+
+
+def test_block_route_known_answers_on_a_path():
+    # the 4-node path with 2 x 2 blocks, written out: A^2 = [[1,0,1,0],[0,2,0,1],[1,0,2,0],[0,1,0,1]]; its four blocks are
+    # diag(1,2), diag(1,1), diag(1,1), diag(2,1): folded onto the corner they add up to diag(5, 5)
+    adj = O.to_symmetric(O.from_edge_index(torch.tensor([[0, 1, 2], [1, 2, 3]]), 4))
+    a2 = O.adj2_by_block(adj, block_size=2)
+    assert a2.to_dense().tolist() == [[1, 0, 1, 0], [0, 2, 0, 1], [1, 0, 2, 0], [0, 1, 0, 1]]
+    folded = O.adj2_by_block(adj, block_size=2, fold_quirk=True)
+    assert folded.to_dense()[:2, :2].tolist() == [[5, 0], [0, 5]] and folded.row.tolist() == [0, 1] and folded.col.tolist() == [0, 1]
+    # a 70-node path with 32-wide blocks (ragged last block): patterns from the closed form above
+    n, bs = 70, 32
+    adj = O.to_symmetric(O.from_edge_index(torch.stack([torch.arange(n - 1), torch.arange(1, n)]), n))
+    full, fold = _path_adj2_patterns(n, bs)
+    a2, fq = O.adj2_by_block(adj, block_size=bs), O.adj2_by_block(adj, block_size=bs, fold_quirk=True)
+    assert set(zip(a2.row.tolist(), a2.col.tolist())) == full
+    assert set(zip(fq.row.tolist(), fq.col.tolist())) == fold

@@ -1106,6 +1106,23 @@ def test_order_sensitive_spmm_known_answer(hiplib, F):
     assert acc.item() == 2.0 ** 24 + 4
 
 
+def test_block_route_known_answers_on_a_path(hiplib):
+    """The ddi block route (int8 MFMA blocks -> bit rows -> CSR) against patterns derived by hand for a path graph: A^2 has
+    (i, i) and (i, i +- 2); with the reference's block-local indices (fold_quirk) every entry lands on
+    (i % block, j % block).  70 nodes, 32-wide blocks: a ragged last block and entries that cross block borders."""
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import block_matrix_multiply
+    n, bs = 70, 32
+    ei = torch.stack([torch.arange(n - 1), torch.arange(1, n)]).to(DEV)
+    adj = SparseTensor.from_edge_index(ei, sparse_sizes=(n, n)).to_symmetric()
+    full = {(i, i) for i in range(n)} | {(i, i + 2) for i in range(n - 2)} | {(i + 2, i) for i in range(n - 2)}
+    fold = {(i % bs, j % bs) for i, j in full}
+    for quirk, want in ((False, full), (True, fold)):
+        a2 = block_matrix_multiply(adj, bs, fold_quirk=quirk)
+        r, c, _ = a2.coo()
+        assert set(zip(r.cpu().tolist(), c.cpu().tolist())) == want
+
+
 def test_eval_caches_follow_parameter_updates(case):
     """The eval fast path caches weight panels and mix coefficients; optimiser-style in-place updates
     (version bump) and .data edits followed by a mode switch must both be seen."""
