@@ -1123,6 +1123,39 @@ def test_block_route_known_answers_on_a_path(hiplib):
         assert set(zip(r.cpu().tolist(), c.cpu().tolist())) == want
 
 
+def test_complete_bipartite_closed_forms(hiplib):
+    """K_{a,b} with a = 1100, b = 1500 (every row longer than 1024: the hub paths of the intersection kernels): every
+    count has a closed form, no oracle involved.  Same-side pair (i, j in A): cn1 = B (b entries), cn2 = empty.  Cross pair
+    (i in A, j in B): cn1 = empty; N2(j) = B, so cn2 = N(i) = B (b entries), and on the walk route each of them is reached by
+    |N(k) n N(j)| = a walks.  Column histograms follow by counting the pairs."""
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import CNState
+    a, b = 1100, 1500
+    n = a + b
+    A, Bs = torch.arange(a), torch.arange(a, n)
+    ei = torch.stack([A.repeat_interleave(b), Bs.repeat(a)]).to(DEV)
+    adj = SparseTensor.from_edge_index(ei, sparse_sizes=(n, n)).to_symmetric()
+    adj2 = product_adj2(adj)
+    g = torch.Generator().manual_seed(5)
+    n_same, n_cross = 37, 53
+    same = torch.stack([torch.randint(0, a, (n_same,), generator=g), torch.randint(0, a, (n_same,), generator=g)])
+    cross = torch.stack([torch.randint(0, a, (n_cross,), generator=g), torch.randint(a, n, (n_cross,), generator=g)])
+    e = torch.cat([same, cross], 1)[:, torch.randperm(n_same + n_cross, generator=g)].contiguous()
+    is_cross = e[1] >= a
+    want1 = torch.where(is_cross, 0, b).tolist()
+    want2 = torch.where(is_cross, b, 0).tolist()
+    for st in (CNState(adj, adj, adj2, e.to(DEV)), CNState(adj, None, None, e.to(DEV), walk=True)):
+        assert st.cnt1.cpu().tolist() == want1 and st.cnt2.cpu().tolist() == want2
+        hc = st.hist_counts().cpu()                       # [N, 4] = n1, n2, n_union, walks
+        assert hc[:a].abs().max().item() == 0             # every source is in A: all entries are columns of B
+        assert hc[a:, 0].unique().tolist() == [n_same] and hc[a:, 1].unique().tolist() == [n_cross]
+        assert hc[a:, 2].unique().tolist() == [n_same + n_cross]
+        if st.walk:
+            assert hc[a:, 3].unique().tolist() == [n_cross * a]
+            wc = st.wc[: int(st.off[-1])].view(-1, b).cpu()   # every source has exactly the b neighbours of side B
+            assert torch.equal(wc, torch.where(is_cross, a, 0).view(-1, 1).expand(-1, b).to(wc.dtype))
+
+
 def test_eval_caches_follow_parameter_updates(case):
     """The eval fast path caches weight panels and mix coefficients; optimiser-style in-place updates
     (version bump) and .data edits followed by a mode switch must both be seen."""
