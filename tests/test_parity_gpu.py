@@ -1156,6 +1156,36 @@ def test_complete_bipartite_closed_forms(hiplib):
             assert torch.equal(wc, torch.where(is_cross, a, 0).view(-1, 1).expand(-1, b).to(wc.dtype))
 
 
+@pytest.mark.parametrize("H", [64, 256])
+def test_complete_bipartite_pooled_vectors_in_closed_form(hiplib, H):
+    """The CN stage end to end without the oracle: K_{1100,1500}, 32 same-side and 64 cross pairs, integer-valued embeddings.
+    Every weight is a power of two (1/32 = 1/S1, 1/64 = 1/S2 of a fresh cn5) and every partial sum an exact fp32 number, so
+    xcn1 = (sum of h over side B) / 32 on same-side rows, xcn2 = (the same sum) / 64 on cross rows (pattern route, cn5) or
+    1100 x that sum (walk route, cn7: raw walk counts), zero elsewhere; x_i * x_j exactly.  All rows are hub rows."""
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import CNState
+    a, b, n_same, n_cross = 1100, 1500, 32, 64
+    n = a + b
+    ei = torch.stack([torch.arange(a).repeat_interleave(b), torch.arange(a, n).repeat(a)]).to(DEV)
+    adj = SparseTensor.from_edge_index(ei, sparse_sizes=(n, n)).to_symmetric()
+    adj2 = product_adj2(adj)
+    g = torch.Generator().manual_seed(H)
+    same = torch.stack([torch.randint(0, a, (n_same,), generator=g), torch.randint(0, a, (n_same,), generator=g)])
+    cross = torch.stack([torch.randint(0, a, (n_cross,), generator=g), torch.randint(a, n, (n_cross,), generator=g)])
+    e = torch.cat([same, cross], 1)[:, torch.randperm(n_same + n_cross, generator=g)].contiguous().to(DEV)
+    is_cross = (e[1] >= a).view(-1, 1)
+    h = torch.randint(-3, 4, (n, H), generator=g).float().to(DEV)
+    sum_b = h[a:].double().sum(0).float().view(1, H)                   # |sum| <= 4500: exact in fp32 in any order
+    zero = torch.zeros(1, H, device=DEV)
+    st = CNState(adj, adj, adj2, e)
+    x1, x2, xij = st.gather(st.weights_cn5(torch.zeros(1, device=DEV)), h)
+    assert torch.equal(x1, torch.where(is_cross, zero, sum_b / 32)) and torch.equal(x2, torch.where(is_cross, sum_b / 64, zero))
+    assert torch.equal(xij, h[e[0]] * h[e[1]])
+    st = CNState(adj, None, None, e, walk=True)
+    x1, x2, _ = st.gather(st.weights_cn7(0.5), h)
+    assert torch.equal(x1, torch.where(is_cross, zero, sum_b / 32)) and torch.equal(x2, torch.where(is_cross, sum_b * a, zero))
+
+
 def test_eval_caches_follow_parameter_updates(case):
     """The eval fast path caches weight panels and mix coefficients; optimiser-style in-place updates
     (version bump) and .data edits followed by a mode switch must both be seen."""
