@@ -1186,6 +1186,34 @@ def test_complete_bipartite_pooled_vectors_in_closed_form(hiplib, H):
     assert torch.equal(x1, torch.where(is_cross, zero, sum_b / 32)) and torch.equal(x2, torch.where(is_cross, sum_b * a, zero))
 
 
+@pytest.mark.parametrize("H", [64, 256])
+def test_large_batch_pooled_vectors_in_closed_form(hiplib, H):
+    """The large-batch path (one-launch prep, processing order, slot records, packed pooling kernel) in closed form:
+    K_{300,500} (rows below the hub threshold), 16384 same-side and 16384 cross pairs -> weights 2^-14, integer embeddings,
+    every partial sum exact."""
+    from ocn_amd.sparse import SparseTensor
+    from ocn_amd.utils import CNState
+    a, b, half = 300, 500, 16384
+    n = a + b
+    ei = torch.stack([torch.arange(a).repeat_interleave(b), torch.arange(a, n).repeat(a)]).to(DEV)
+    adj = SparseTensor.from_edge_index(ei, sparse_sizes=(n, n)).to_symmetric()
+    adj2 = product_adj2(adj)
+    g = torch.Generator().manual_seed(H + 1)
+    same = torch.stack([torch.randint(0, a, (half,), generator=g), torch.randint(0, a, (half,), generator=g)])
+    cross = torch.stack([torch.randint(0, a, (half,), generator=g), torch.randint(a, n, (half,), generator=g)])
+    e = torch.cat([same, cross], 1)[:, torch.randperm(2 * half, generator=g)].contiguous().to(DEV)
+    is_cross = (e[1] >= a).view(-1, 1)
+    h = torch.randint(-3, 4, (n, H), generator=g).float().to(DEV)
+    sum_b = h[a:].double().sum(0).float().view(1, H)
+    zero = torch.zeros(1, H, device=DEV)
+    st = CNState(adj, adj, adj2, e)
+    assert st.order is not None and st.rec is not None
+    assert st.cnt1.tolist() == torch.where(is_cross.view(-1), 0, b).tolist()
+    x1, x2, xij = st.gather(st.weights_cn5(torch.zeros(1, device=DEV)), h)
+    assert torch.equal(x1, torch.where(is_cross, zero, sum_b / half)) and torch.equal(x2, torch.where(is_cross, sum_b / half, zero))
+    assert torch.equal(xij, h[e[0]] * h[e[1]])
+
+
 def test_eval_caches_follow_parameter_updates(case):
     """The eval fast path caches weight panels and mix coefficients; optimiser-style in-place updates
     (version bump) and .data edits followed by a mode switch must both be seen."""
