@@ -61,6 +61,16 @@ def _worker(rank, world, port, B, out):
         mine = (torch.arange(s, e, dtype=torch.float32) * 0.5 + 1).reshape(-1, 1)
         allsc = gather_scores(mine, B)
         ok_gather = torch.equal(allsc, (torch.arange(B, dtype=torch.float32) * 0.5 + 1).reshape(-1, 1))
+        # the split forms used by the pipelined scoring loop: on gloo / host tensors they complete at once
+        from ocn_amd.dist import allreduce_hist_finish, allreduce_hist_start
+        pk2 = pk.clone()
+        handle = allreduce_hist_start(pk2, valued=True)
+        allreduce_hist_finish(handle)
+        ok_hist &= handle is None and bool((pk2[:, 1] == 7 * world + sum(range(world))).all())
+        again, work = gather_scores(mine, B, async_op=True)
+        if work is not None:
+            work.wait()
+        ok_gather &= torch.equal(again, allsc)
         out.put((rank, ok_hist, ok_gather, tuple(allsc.shape)))
     finally:
         dist.destroy_process_group()
