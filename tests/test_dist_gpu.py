@@ -42,6 +42,23 @@ def _worker(rank, world, port, q):
         args = SimpleNamespace(sum=2.74)
         with torch.no_grad():
             out = {k: sharded_predict(p, h, adj, adj2, edges, args).cpu().numpy() for k, p in preds.items()}
+            # the scoring loop's form: two batches in flight (begin / finish), one gather per batch here
+            from ocn_amd.dist import gather_scores, shard_bounds
+            from ocn_amd.utils import adjoverlap
+            batches = [edges, edges.flip(1).contiguous()]
+            s, e = shard_bounds(edges.shape[1], world)[rank]
+            for k, p in preds.items():
+                p.set_edge_sharding(None, enabled=True)
+                try:
+                    mine = [b[:, s:e].contiguous() for b in batches]
+                    tok = p.begin(h, adj, adjoverlap(adj, adj, mine[0]), adjoverlap(adj, adj2, mine[0]), mine[0], slot=0)
+                    nxt = p.begin(h, adj, adjoverlap(adj, adj, mine[1]), adjoverlap(adj, adj2, mine[1]), mine[1], slot=1)
+                    loc0 = p.finish(h, tok, args)
+                    loc1 = p.finish(h, nxt, args)
+                finally:
+                    p.set_edge_sharding(None, enabled=False)
+                out[k + "_pipe0"] = gather_scores(loc0, edges.shape[1]).cpu().numpy()
+                out[k + "_pipe1"] = gather_scores(loc1, edges.shape[1]).cpu().numpy()
         q.put((rank, out))                       # numpy: pickled by value (a tensor would travel as a shared-memory handle of a process that exits)
     finally:
         dist.destroy_process_group()
@@ -55,6 +72,10 @@ def test_two_ranks_on_one_gpu_equal_single_process(hiplib):
     with torch.no_grad():
         single = {k: p(h, adj, adjoverlap(adj, adj, edges), adjoverlap(adj, adj2, edges), edges, args).cpu()
                   for k, p in preds.items()}
+        rev = edges.flip(1).contiguous()
+        for k, p in preds.items():
+            single[k + "_pipe0"] = single[k]
+            single[k + "_pipe1"] = p(h, adj, adjoverlap(adj, adj, rev), adjoverlap(adj, adj2, rev), rev, args).cpu()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
