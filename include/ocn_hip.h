@@ -27,8 +27,9 @@ extern "C" {
 
 /* ABI history — 2: workspaces zero on entry / left zero, ocn_check_edges, ocn_zero_regions, ocn_cn_colsum_exact, walk prep /
  * group entries, dense block route, ocn_heads_fused; 3: ocn_cn_flags takes bit rows of T1, ocn_bitrows_from_csr;
- * 4: ocn_batch_prep, ocn_order_by_node_finish; 5: slot records (`rec`) from ocn_cn_flags to ocn_cn_gather. */
-#define OCN_ABI_VERSION 5
+ * 4: ocn_batch_prep, ocn_order_by_node_finish; 5: slot records (`rec`) from ocn_cn_flags to ocn_cn_gather;
+ * 6: ocn_heads_fused on f16 hi/lo panels (ocn_heads_split_weight replaces ocn_linear_split_weight_chained). */
+#define OCN_ABI_VERSION 6
 #define OCN_EINVAL (-1)   /* null pointer / negative size / unsupported combination */
 #define OCN_ECAP   (-2)   /* reported through the device status word: flags capacity too small */
 
@@ -391,14 +392,18 @@ int ocn_linear_grouped(const OcnLinearGroup* groups, int32_t n_groups, int32_t K
  * where the host has folded the reference's products without a non-linearity between them — the third layers
  * of xcn1lin / xcn2lin, the second layer of xijlin, the mix alpha0*xcn1 + alpha1*xcn2 + beta*xij (model.py:2436)
  * and lin[0] — into Ma, Mb, Mc, bf.  Every activation stays in registers; only x[3] is read and y written.
- * p_first: natural panels (ocn_linear_split_weight) of xcn1lin.0, xcn2lin.0, xijlin.0; p_mid: CHAINED panels
- * (ocn_linear_split_weight_chained) of xcn1lin.3, xcn2lin.3; p_out: chained panels of Ma, Mb, Mc.
+ * An f32 product is three f16 MFMAs on hi/lo splits of both operands (v_mfma_f32_32x32x16_f16, fp32 accumulate):
+ * ocn_heads_split_weight writes the panel of scale * W (scale = a power of two that puts max |W| into
+ * [2^13, 2^14); ocn_heads_panel_bytes(N, K) bytes) in the k order in which the previous layer's accumulator
+ * registers arrive; activation rows are scaled per row inside the kernel.
+ * p_first: panels of xcn1lin.0, xcn2lin.0, xijlin.0; p_mid: of xcn1lin.3, xcn2lin.3; p_out: of Ma, Mb, Mc.
  * vec: ocn_heads_nvec() vectors of H floats — b0a b3a g3a e3a  b0b b3b g3b e3b  b0x gx ex  bf gl el  dotw  constA constB
- * — followed by the dot bias; constA / constB = Ma a, Mb b of an all-zero pooled row, obtained from this entry in
- * dump mode (dump != NULL: one workgroup, row 0, writes dump[0][H], dump[1][H], no scores).  ranges (or NULL) =
- * ocn_class_order's table: the candidates then come class-major and a workgroup without any cn1 (cn2) row adds the
- * constant instead of running the branch; b_on_union: cn5 (xcn2 lives on cn1 u cn2) vs cn7 (cn2 only).
- * H in {32, 64, 128, 256}; in_channels == H. */
+ * — followed by ocn_heads_nscal() scalars: the dot bias, then 1 / scale of the eight panels in the order
+ * xcn1lin.0 xcn1lin.3 Ma xcn2lin.0 xcn2lin.3 Mb xijlin.0 Mc, then zeros.  constA / constB = Ma a, Mb b of an all-zero
+ * pooled row, obtained from this entry in dump mode (dump != NULL: one workgroup, row 0, writes dump[0][H],
+ * dump[1][H], no scores).  ranges (or NULL) = ocn_class_order's table: the candidates then come class-major and a
+ * workgroup without any cn1 (cn2) row adds the constant instead of running the branch; b_on_union: cn5 (xcn2 lives on
+ * cn1 u cn2) vs cn7 (cn2 only).  H in {128, 256}; in_channels == H (narrower heads: ocn_linear_grouped). */
 typedef struct OcnHeadsArgs {
   const float* x[3];
   int64_t ldx, B;
@@ -411,13 +416,15 @@ typedef struct OcnHeadsArgs {
   const int64_t* y_row_map;
   float* y;
   float* dump;
-  float* scratch;            /* ocn_heads_scratch_bytes(H) bytes: where a wave parks a finished branch's accumulators */
+  float* scratch;            /* ocn_heads_scratch_bytes(H) bytes: where a wave parks a finished branch's share of the output */
   float eps;
   int32_t ln, b_on_union;
 } OcnHeadsArgs;
 int32_t ocn_heads_nvec(void);
+int32_t ocn_heads_nscal(void);
 int64_t ocn_heads_scratch_bytes(int32_t H);
-int ocn_linear_split_weight_chained(const float* W, int32_t N, int32_t K, void* Wp, void* stream);
+int64_t ocn_heads_panel_bytes(int32_t N, int32_t K);
+int ocn_heads_split_weight(const float* W, int32_t N, int32_t K, float scale, void* Wp, void* stream);
 int ocn_heads_fused(const OcnHeadsArgs* args, void* stream);
 
 #ifdef __cplusplus

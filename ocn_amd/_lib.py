@@ -19,7 +19,7 @@ INCLUDE = os.path.join(_ROOT, "include")
 
 # name -> (restype, argtypes); must list every symbol include/ocn_hip.h declares
 _P = c_void_p
-ABI_VERSION = 5
+ABI_VERSION = 6
 SIGNATURES = {
     "ocn_abi_version": (c_int32, []),
     "ocn_scan_workspace_bytes": (c_int64, [c_int64]),
@@ -72,8 +72,10 @@ SIGNATURES = {
                                     _P, _P]),
     "ocn_linear_grouped": (c_int32, [_P, c_int32, c_int32, c_int32, _P]),
     "ocn_heads_nvec": (c_int32, []),
+    "ocn_heads_nscal": (c_int32, []),
     "ocn_heads_scratch_bytes": (c_int64, [c_int32]),
-    "ocn_linear_split_weight_chained": (c_int32, [_P, c_int32, c_int32, _P, _P]),
+    "ocn_heads_panel_bytes": (c_int64, [c_int32, c_int32]),
+    "ocn_heads_split_weight": (c_int32, [_P, c_int32, c_int32, c_float, _P, _P]),
     "ocn_heads_fused": (c_int32, [_P, _P]),
 }
 

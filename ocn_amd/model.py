@@ -839,10 +839,16 @@ class _CNPredictorBase(nn.Module):
             vecs = [sa[0][0].bias, sa[1][0].bias, *gb(sa[1][1]), sb[0][0].bias, sb[1][0].bias, *gb(sb[1][1]),
                     sx[0][0].bias, *gb(sx[0][1]), bf.float(), *gb(sl[1]), tail.weight.reshape(-1), zeros, zeros]
             assert len(vecs) == int(ops._lib.lib().ocn_heads_nvec())
-            vec = torch.cat([v.detach().float().reshape(-1) for v in vecs] + [tail.bias.detach().float().reshape(1)]).contiguous()
-            pack = dict(first=[ops.linear_panel(sa[0][0].weight), ops.linear_panel(sb[0][0].weight), ops.linear_panel(sx[0][0].weight)],
-                        mid=[ops.linear_panel_chained(sa[1][0].weight), ops.linear_panel_chained(sb[1][0].weight)],
-                        out=[ops.linear_panel_chained(m.float().contiguous()) for m in (Ma, Mb, Mc)],
+            # f16 hi/lo panels in the order of the kernel's stream: xcn1lin.0 .3 Ma | xcn2lin.0 .3 Mb | xijlin.0 Mc
+            pans = [ops.heads_panel(m.float().contiguous()) for m in
+                    (sa[0][0].weight, sa[1][0].weight, Ma, sb[0][0].weight, sb[1][0].weight, Mb, sx[0][0].weight, Mc)]
+            nscal = int(ops._lib.lib().ocn_heads_nscal())
+            scal = torch.zeros(nscal, device=dev)
+            scal[0] = tail.bias.detach().float().reshape(())
+            scal[1:9] = torch.tensor([p[1] for p in pans], device=dev)
+            vec = torch.cat([v.detach().float().reshape(-1) for v in vecs] + [scal]).contiguous()
+            pack = dict(first=[pans[0][0], pans[3][0], pans[6][0]], mid=[pans[1][0], pans[4][0]],
+                        out=[pans[2][0], pans[5][0], pans[7][0]],
                         vec=vec, ln=ln, eps=(sa[1][1].eps if ln else 1e-5), flops_per_row=2.0 * H * H * 8)
             # the constants a skipped branch contributes: the branch's share of the output on an all-zero pooled row,
             # computed by the kernel itself (dump mode) so that skipping changes no bit

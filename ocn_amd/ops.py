@@ -673,17 +673,24 @@ def linear_panel(weight: Tensor) -> Tensor:
 
 
 @_on_device
-def linear_panel_chained(weight: Tensor) -> Tensor:
-    """The CHAINED panel of a weight [N, K] (ocn_hip.h: ocn_linear_split_weight_chained): the k order in which the
-    previous layer's accumulator registers arrive in ocn_heads_fused.  Not cached here (the heads pack caches it)."""
+def heads_panel(weight: Tensor):
+    """The f16 hi/lo panel of a weight [N, K] for ocn_heads_fused (ocn_hip.h: ocn_heads_split_weight) and the inverse of
+    the power of two it was scaled by (max |scale * W| in [2^13, 2^14): f16 has a 5-bit exponent).  Not cached here
+    (the heads pack caches it); one host sync for the maximum."""
+    import math
     w = _req(weight.detach(), torch.float32, "weight", 2)
     N, K = w.shape
-    panel = torch.empty(int(_lib.lib().ocn_linear_panel_bytes(N, K)), dtype=torch.uint8, device=w.device)
-    check(_lib.lib().ocn_linear_split_weight_chained(ptr(w), N, K, ptr(panel), stream_ptr()), "ocn_linear_split_weight_chained")
-    return panel
+    m = float(w.abs().max().item()) if w.numel() else 0.0
+    if not math.isfinite(m):
+        raise ValueError("heads_panel: non-finite weight")
+    sw = 13 - math.frexp(m)[1] + 1 if m > 0.0 else 0          # frexp: m = f * 2^e, f in [0.5, 1)  ->  floor(log2 m) = e - 1
+    sw = max(-100, min(100, sw))
+    panel = torch.empty(int(_lib.lib().ocn_heads_panel_bytes(N, K)), dtype=torch.uint8, device=w.device)
+    check(_lib.lib().ocn_heads_split_weight(ptr(w), N, K, float(2.0 ** sw), ptr(panel), stream_ptr()), "ocn_heads_split_weight")
+    return panel, float(2.0 ** -sw)
 
 
-HEADS_WIDTHS = (32, 64, 128, 256)
+HEADS_WIDTHS = (128, 256)
 train_linear = True              # autograd on: the heads' Linear layers (forward and input gradient) on the MFMA kernel
 fused_heads = True               # cn5 / cn7 eval: the whole MLP head as one launch (ocn_heads_fused)
 fused_heads_min_width = 128      # narrower heads (ppa / citation2 / ddi: H = 32..64) have a k-loop of 2-4 steps: the fused

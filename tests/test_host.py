@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(hiplib):
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
     for n in names:
         assert getattr(hiplib, n) is not None
-    assert hiplib.ocn_abi_version() == _lib.ABI_VERSION == 5
+    assert hiplib.ocn_abi_version() == _lib.ABI_VERSION == 6
     assert hiplib.ocn_scan_workspace_bytes(65536) >= 8 * (65536 // 2048 + 2)
     assert hiplib.ocn_spgemm_max_cols() >= 1_000_000
 
@@ -41,8 +41,12 @@ def test_entries_reject_bad_arguments_before_any_launch(hiplib):
     assert hiplib.ocn_heads_fused(NULL, NULL) == E
     args = _lib.OcnHeadsArgs()                                     # all-NULL pointers, H = 0
     assert hiplib.ocn_heads_fused(ctypes.byref(args), NULL) == E
-    assert hiplib.ocn_linear_split_weight_chained(NULL, 256, 256, NULL, NULL) == E
-    assert hiplib.ocn_linear_split_weight_chained(p, 250, 256, p, NULL) == E               # N not a multiple of 32
+    args.H, args.B = 64, 4                                         # a width the fused kernel is not built for
+    assert hiplib.ocn_heads_fused(ctypes.byref(args), NULL) == E
+    assert hiplib.ocn_heads_split_weight(NULL, 256, 256, 1.0, NULL, NULL) == E
+    assert hiplib.ocn_heads_split_weight(p, 250, 256, 1.0, p, NULL) == E                    # N not a multiple of 32
+    assert hiplib.ocn_heads_split_weight(p, 256, 256, 0.0, p, NULL) == E                    # scale must be positive
+    assert hiplib.ocn_heads_panel_bytes(256, 256) == 256 * 256 * 4 and hiplib.ocn_heads_panel_bytes(250, 256) == 0
     assert hiplib.ocn_cn_colsum_exact(NULL, NULL, NULL, -1, NULL, NULL, NULL, NULL, 0, NULL, 0, NULL, NULL, NULL, NULL, NULL,
                                       NULL, NULL) == E
     assert hiplib.ocn_cn_colsum_exact(p, p, p, 4, p, p, NULL, NULL, 1 << 33, p, 4, p, p, NULL, p, NULL, p, NULL) == E   # flags_cap >= 2^32
@@ -209,3 +213,17 @@ def test_adjoverlap_signature_and_unsupported_branches():
     assert h.sizes() == [2, 3]
     with pytest.raises(NotImplementedError):
         adjoverlap(adj, adj, torch.tensor([[0], [1]]), calresadj=True)
+
+
+def test_heads_kernel_isa_audit():
+    """The fused heads' k-step is hand-placed inline asm whose waits are counted by hand (heads.hip).  tools/check_heads_asm.py
+    compiles it and checks the ISA: no instruction touches the destination of an LDS read the lgkmcnt ladder has not
+    retired, no VALU result feeds an MFMA within two wait states, no reader of an MFMA result within twelve, no scratch."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("check_heads_asm", os.path.join(os.path.dirname(__file__), "..", "tools", "check_heads_asm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    problems, stats = mod.audit(mod.compile_asm())
+    assert len(stats) == 2 and all(s["mfma"] > 0 and s["ds_read"] > 0 for s in stats.values())
+    assert not problems, problems[:5]

@@ -18,7 +18,7 @@ if flags:
 import ocn_amd.model as M  # noqa: E402
 
 dev = torch.device("cuda:0")
-for H, B in ((256, 65536), (64, 32768)):
+for H, B in ((256, 65536), (128, 32768)):
     torch.manual_seed(0)
     pred = M.predictor_dict["cn5"](H, H, 1, 3, 0.0, 0.0, True).to(dev).eval()
     x1, x2, xij = (torch.randn(B, H, device=dev) for _ in range(3))
