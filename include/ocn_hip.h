@@ -399,9 +399,10 @@ int ocn_linear_grouped(const OcnLinearGroup* groups, int32_t n_groups, int32_t K
  * p_first: panels of xcn1lin.0, xcn2lin.0, xijlin.0; p_mid: of xcn1lin.3, xcn2lin.3; p_out: of Ma, Mb, Mc.
  * vec: ocn_heads_nvec() vectors of H floats — b0a b3a g3a e3a  b0b b3b g3b e3b  b0x gx ex  bf gl el  dotw  constA constB
  * — followed by ocn_heads_nscal() scalars: the dot bias, then 1 / scale of the eight panels in the order
- * xcn1lin.0 xcn1lin.3 Ma xcn2lin.0 xcn2lin.3 Mb xijlin.0 Mc, then zeros.  constA / constB = Ma a, Mb b of an all-zero
- * pooled row, obtained from this entry in dump mode (dump != NULL: one workgroup, row 0, writes dump[0][H],
- * dump[1][H], no scores).  ranges (or NULL) = ocn_class_order's table: the candidates then come class-major and a
+ * xcn1lin.0 xcn1lin.3 Ma xcn2lin.0 xcn2lin.3 Mb xijlin.0 Mc, then zeros (constA / constB are unused since ABI 6).
+ * What a skipped branch contributes — Ma a, Mb b of an all-zero pooled row — comes from this entry in constants mode
+ * (dump != NULL, B == 1, x = one zero row: fills ocn_heads_const_bytes(H) bytes, no score) and is handed back as
+ * `cpark` in scoring mode.  ranges (or NULL) = ocn_class_order's table: the candidates then come class-major and a
  * workgroup without any cn1 (cn2) row adds the constant instead of running the branch; b_on_union: cn5 (xcn2 lives on
  * cn1 u cn2) vs cn7 (cn2 only).  H in {128, 256}; in_channels == H (narrower heads: ocn_linear_grouped). */
 typedef struct OcnHeadsArgs {
@@ -415,7 +416,8 @@ typedef struct OcnHeadsArgs {
   const int64_t* ranges;
   const int64_t* y_row_map;
   float* y;
-  float* dump;
+  float* dump;               /* constants mode: ocn_heads_const_bytes(H) bytes out, B == 1 */
+  const float* cpark;        /* scoring mode: the buffer a constants-mode call filled */
   float* scratch;            /* ocn_heads_scratch_bytes(H) bytes: where a wave parks a finished branch's share of the output */
   float eps;
   int32_t ln, b_on_union;
@@ -423,6 +425,7 @@ typedef struct OcnHeadsArgs {
 int32_t ocn_heads_nvec(void);
 int32_t ocn_heads_nscal(void);
 int64_t ocn_heads_scratch_bytes(int32_t H);
+int64_t ocn_heads_const_bytes(int32_t H);
 int64_t ocn_heads_panel_bytes(int32_t N, int32_t K);
 int ocn_heads_split_weight(const float* W, int32_t N, int32_t K, float scale, void* Wp, void* stream);
 int ocn_heads_fused(const OcnHeadsArgs* args, void* stream);

@@ -74,6 +74,7 @@ SIGNATURES = {
     "ocn_heads_nvec": (c_int32, []),
     "ocn_heads_nscal": (c_int32, []),
     "ocn_heads_scratch_bytes": (c_int64, [c_int32]),
+    "ocn_heads_const_bytes": (c_int64, [c_int32]),
     "ocn_heads_panel_bytes": (c_int64, [c_int32, c_int32]),
     "ocn_heads_split_weight": (c_int32, [_P, c_int32, c_int32, c_float, _P, _P]),
     "ocn_heads_fused": (c_int32, [_P, _P]),
@@ -98,7 +99,7 @@ class OcnHeadsArgs(ctypes.Structure):
     _fields_ = [("x", c_void_p * 3), ("ldx", c_int64), ("B", c_int64), ("H", c_int32),
                 ("p_first", c_void_p * 3), ("p_mid", c_void_p * 2), ("p_out", c_void_p * 3),
                 ("vec", c_void_p), ("ranges", c_void_p), ("y_row_map", c_void_p), ("y", c_void_p),
-                ("dump", c_void_p), ("scratch", c_void_p), ("eps", c_float), ("ln", c_int32), ("b_on_union", c_int32)]
+                ("dump", c_void_p), ("cpark", c_void_p), ("scratch", c_void_p), ("eps", c_float), ("ln", c_int32), ("b_on_union", c_int32)]
 
 
 def sources():

@@ -61,7 +61,8 @@ struct HeadsArgs {
   const i64* ranges;                  // ocn_class_order's range table, or NULL (every row runs every branch)
   const i64* y_row_map;               // destination row of a score, or NULL
   float* y;
-  float* dump;                        // constants mode: [2][H] <- the branch outputs Ma a, Mb b of row 0
+  float* dump;                        // constants mode: [2][4 NT][64] float4 <- the shares Ma a, Mb b of row 0, in the park layout
+  const float* cpark;                 // ... which come back here: what a skipped branch contributes
   float* scratch;                     // ocn_heads_scratch_bytes(): two parked branch shares per resident wave
   float eps;
   int ln, b_on_union;
@@ -75,27 +76,19 @@ template <int N, typename F>
 __device__ __forceinline__ void hd_unroll(F&& f) { hd_unroll_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // ---- the instruction groups of a k-step (cdna_hip_programming.md §5.7: the compiler neither counts the memory
-// operations of an asm statement nor pads its hazards; every wait below is counted by hand, see hd_layer) -----------
+// operations of an asm statement nor pads its hazards; every wait below is counted by hand, see Heads::layer; the
+// ISA is audited by tools/check_heads_asm.py) --------------------------------------------------------------------
 
-// acc (+)= A . B after at most N LDS reads are still outstanding (N < 0: no wait); CZ: the accumulator starts at 0
-template <bool ACC_A, bool CZ, int N>
+// acc (+)= A . B after at most N LDS reads are still outstanding (N < 0: no wait); CZ: the accumulator starts at 0.
+// The accumulators live in the accumulator file ("a").
+template <bool CZ, int N>
 __device__ __forceinline__ void hd_mfma(f32x16& c, const h16x8& a, const h16x8& b) {
-  if constexpr (ACC_A) {
-    if constexpr (CZ) {
-      if constexpr (N >= 0) asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b), "i"(N));
-      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
-    } else {
-      if constexpr (N >= 0) asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b), "i"(N));
-      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
-    }
+  if constexpr (CZ) {
+    if constexpr (N >= 0) asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b), "i"(N));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
   } else {
-    if constexpr (CZ) {
-      if constexpr (N >= 0) asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b), "i"(N));
-      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
-    } else {
-      if constexpr (N >= 0) asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b), "i"(N));
-      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
-    }
+    if constexpr (N >= 0) asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b), "i"(N));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
   }
 }
 
@@ -107,15 +100,9 @@ __device__ __forceinline__ void hd_dsread(h16x8& f, unsigned addr) {
 }
 
 // operand split of two activations, first half: t = x * sc, H = f16x2(t0, t1), t2 = f32(H.lo)
-template <bool IN_A>
 __device__ __forceinline__ void hd_split1(float x0, float x1, float sc, unsigned& H, float& t0, float& t1, float& t2) {
-  if constexpr (IN_A)
-    asm volatile("v_accvgpr_read_b32 %1, %4\n\tv_accvgpr_read_b32 %2, %5\n\tv_mul_f32 %1, %1, %6\n\tv_mul_f32 %2, %2, %6\n\t"
-                 "v_cvt_pk_f16_f32 %0, %1, %2\n\tv_cvt_f32_f16 %3, %0"
-                 : "=&v"(H), "=&v"(t0), "=&v"(t1), "=&v"(t2) : "a"(x0), "a"(x1), "v"(sc));
-  else
-    asm volatile("v_mul_f32 %1, %4, %6\n\tv_mul_f32 %2, %5, %6\n\tv_cvt_pk_f16_f32 %0, %1, %2\n\tv_cvt_f32_f16 %3, %0"
-                 : "=&v"(H), "=&v"(t0), "=&v"(t1), "=&v"(t2) : "v"(x0), "v"(x1), "v"(sc));
+  asm volatile("v_mul_f32 %1, %4, %6\n\tv_mul_f32 %2, %5, %6\n\tv_cvt_pk_f16_f32 %0, %1, %2\n\tv_cvt_f32_f16 %3, %0"
+               : "=&v"(H), "=&v"(t0), "=&v"(t1), "=&v"(t2) : "v"(x0), "v"(x1), "v"(sc));
 }
 // second half: L = f16x2(t0 - f32(H.lo), t1 - f32(H.hi))   (the differences are exact)
 __device__ __forceinline__ void hd_split2(unsigned H, float t0, float t1, float t2, unsigned& L) {
@@ -133,6 +120,13 @@ __device__ __forceinline__ void hd_dma(unsigned voff, const char* base, unsigned
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds) : "memory");
 #endif
+}
+
+// 16 bytes of a lane's input row; `v` is in flight until hd_xwait
+template <int OFF>
+__device__ __forceinline__ void hd_xload(f32x4& v, const float* row) {
+  static_assert(OFF >= 0 && OFF < 4096, "global offset");
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(v) : "v"(row), "i"(OFF) : "memory");
 }
 
 // my pieces of the next chunk have landed (all but the N youngest vector-memory operations are done), then everybody's
@@ -155,6 +149,11 @@ __device__ __forceinline__ void hd_row_scale(float m, float pinv, float& sc, flo
   sc = __uint_as_float((267u - e) << 23);
   inv = __uint_as_float((e - 13u) << 23) * pinv;
 }
+
+__device__ __forceinline__ f32x4 hd_lds4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ float hd_max4(float m, f32x4 v) { return fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3])); }
+__device__ __forceinline__ f32x4 hd_grp(const f32x16& v, int g) { return f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}; }
+#define HD_GRP(v, g) hd_grp(v, g)
 
 template <int NT>
 struct Heads {
@@ -184,27 +183,43 @@ struct Heads {
     unsigned ld[3];                   // per wave: byte address of the wave's first LDS-DMA piece in the slot
   };
 
-  static __device__ __forceinline__ void pin_a(f32x16 (&v)[NT]) {
+  // The three register sets of a wave.  in[4 t + g][j] = feature 32 t + 8 g + 4 hh + j of the lane's candidate: the
+  // layer's input (arch VGPRs; the accumulator layout, register 4 g + j of tile t, in groups of four).  acc: the layer's
+  // output; sum: the branches' shares of the last layer's input — both in the accumulator file.
+  typedef f32x4 In[4 * NT];
+  typedef f32x16 Acc[NT];
+
+  static __device__ __forceinline__ void pin_in(In& v) {
+#pragma unroll
+    for (int t = 0; t < 4 * NT; ++t) asm volatile("" : "+v"(v[t]));
+  }
+  static __device__ __forceinline__ void pin_acc(Acc& v) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) asm volatile("" : "+a"(v[t]));
   }
-  static __device__ __forceinline__ void pin_v(f32x16 (&v)[NT]) {
+
+  // the prefetched rows have landed
+  static __device__ __forceinline__ void xwait(In& v) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
+                 : : "memory");
 #pragma unroll
-    for (int t = 0; t < NT; ++t) asm volatile("" : "+v"(v[t]));
+    for (int t = 8; t < 4 * NT; t += 8)
+      asm volatile("" : "+v"(v[t]), "+v"(v[t + 1]), "+v"(v[t + 2]), "+v"(v[t + 3]), "+v"(v[t + 4]), "+v"(v[t + 5]), "+v"(v[t + 6]), "+v"(v[t + 7]));
   }
 
-  // acc = Wp . in on the 32 candidates of this wave.  `in` holds the layer's input in accumulator layout (tile tt,
-  // register i = feature 32 tt + (i & 3) + 8 (i >> 2) + 4 hh), `sc` the row's scale.  The weight stream: this layer's
-  // panel p_cur (its chunk c is in ring role c % 3), then p_nxt; LAST: the stream ends with this layer.
-  template <bool ACC_A, bool IN_A, bool LAST>
-  static __device__ __forceinline__ void layer(f32x16 (&acc)[NT], f32x16 (&in)[NT], float sc, Ring& rg, const char* p_cur,
-                                               const char* p_nxt, unsigned lane16) {
+  // acc = Wp . in on the 32 candidates of this wave; `sc` = the row's scale.  The weight stream: this layer's panel
+  // p_cur (its chunk c is in ring role c % 3), then p_nxt; LAST: the stream ends with this layer.  XP: the 16 registers
+  // of input tile c are dead once chunk c has split its second k-step — they receive tile c of the NEXT input rows
+  // (xnext: the lane's row + 4 hh floats), so that the next first layer finds its input in registers.
+  template <bool LAST, bool XP>
+  static __device__ __forceinline__ void layer(Acc& acc, In& in, float sc, Ring& rg, const char* p_cur, const char* p_nxt,
+                                               unsigned lane16, const float* xnext) {
     h16x8 fh[4], fl[4];
     unsigned xb[2][2][4];             // [k-step parity][hi, lo][4 registers]: the B operand
 #pragma unroll
     for (int p = 0; p < 4; ++p) {     // operand of k-step 0
       float t0, t1, t2;
-      hd_split1<IN_A>(in[0][2 * p], in[0][2 * p + 1], sc, xb[0][0][p], t0, t1, t2);
+      hd_split1(in[p >> 1][2 * (p & 1)], in[p >> 1][2 * (p & 1) + 1], sc, xb[0][0][p], t0, t1, t2);
       hd_split2(xb[0][0][p], t0, t1, t2, xb[0][1][p]);
     }
     hd_dsread<0>(fh[0], rg.pa[0]);
@@ -220,110 +235,130 @@ struct Heads {
       constexpr int g3 = g + 3, c3 = g3 / TPC, q3 = g3 % TPC, f3 = g3 % 4;
       constexpr bool pf = g3 < G;                                      // fragments of the tile three steps ahead
       constexpr bool sp = s + 1 < KS && t < 4;                         // a quarter of the next k-step's operand
-      constexpr int sn = s + 1;
+      constexpr int sn = s + 1, si = 4 * (sn / 2) + 2 * (sn & 1) + (t >> 1), sj = 2 * (t & 1);
       // the chunk boundary, three tile steps early (the first read of the next chunk is this step's prefetch): the
       // pieces of the next chunk were issued a chunk ago; younger are only the pieces this chunk has issued so far
       if constexpr (q == TPC - 3 && !(LAST && c == NCH - 1)) hd_sync<(LAST && c + 2 >= NCH) ? 0 : piece_of(TPC - 3)>();
       // LDS reads are issued in the order hi(0) lo(0) hi(1) lo(1) ...: read 2g must be back before the first MFMA
       constexpr int issued1 = 2 * (g + 3) < 2 * G ? 2 * (g + 3) : 2 * G;
-      hd_mfma<ACC_A, s == 0, issued1 - (2 * g + 1)>(acc[t], fh[f], hd_frag(xb[s & 1][1]));          // wh . xl
+      hd_mfma<s == 0, issued1 - (2 * g + 1)>(acc[t], fh[f], hd_frag(xb[s & 1][1]));                 // wh . xl
       if constexpr (pf) hd_dsread<q3 * 2048>(fh[f3], rg.pa[c3 % 3]);
-      if constexpr (sp) hd_split1<IN_A>(in[sn / 2][8 * (sn & 1) + 2 * t], in[sn / 2][8 * (sn & 1) + 2 * t + 1], sc,
-                                        xb[sn & 1][0][t], st0[t], st1[t], st2[t]);
+      if constexpr (sp) hd_split1(in[si][sj], in[si][sj + 1], sc, xb[sn & 1][0][t], st0[t], st1[t], st2[t]);
       constexpr int issued2 = pf ? 2 * g3 + 1 : 2 * G;
-      hd_mfma<ACC_A, false, issued2 - (2 * g + 2)>(acc[t], fl[f], hd_frag(xb[s & 1][0]));           // wl . xh
+      hd_mfma<false, issued2 - (2 * g + 2)>(acc[t], fl[f], hd_frag(xb[s & 1][0]));                  // wl . xh
       if constexpr (pf) hd_dsread<q3 * 2048 + 1024>(fl[f3], rg.pa[c3 % 3]);
       if constexpr (sp) hd_split2(xb[sn & 1][0][t], st0[t], st1[t], st2[t], xb[sn & 1][1][t]);
-      hd_mfma<ACC_A, false, -1>(acc[t], fh[f], hd_frag(xb[s & 1][0]));                               // wh . xh
+      hd_mfma<false, -1>(acc[t], fh[f], hd_frag(xb[s & 1][0]));                                      // wh . xh
       // one piece of the chunk two ahead behind the tile steps that carry no operand split
       if constexpr (has_piece(q) && !(LAST && c + 2 >= NCH)) {
         constexpr int c2 = c + 2, j = piece_of(q);
         const char* src = (c2 < NCH ? p_cur + (size_t)c2 * CHB : p_nxt + (size_t)(c2 - NCH) * CHB) + (size_t)j * 4096;
         hd_dma(lane16, src, rg.ld[c2 % 3] + j * 4096);
       }
+      // the next rows' tile c into the registers of this layer's input tile c (last read: step 3 of chunk c)
+      if constexpr (XP && q >= 4 && q < 8) hd_xload<(32 * c + 8 * (q - 4)) * 4>(in[4 * c + (q - 4)], xnext);
     });
     // the last MFMAs' results must not be read by the epilogue's VALU for 12 wait states (§5.7 item 2); every tile
     // is an operand of the fence, or the compiler hoists the epilogue's first reads above the last k-step's MFMAs
-    if constexpr (ACC_A) {
-      asm volatile("s_nop 15" : "+a"(acc[0])::"memory");
+    asm volatile("s_nop 15" : "+a"(acc[0])::"memory");
 #pragma unroll
-      for (int t = 1; t < NT; ++t) asm volatile("" : "+a"(acc[t]));
-    } else {
-      asm volatile("s_nop 15" : "+v"(acc[0])::"memory");
-#pragma unroll
-      for (int t = 1; t < NT; ++t) asm volatile("" : "+v"(acc[t]));
-    }
+    for (int t = 1; t < NT; ++t) asm volatile("" : "+a"(acc[t]));
+    if constexpr (XP) xwait(in);
     const Ring o = rg;                // the roles after NCH chunks
 #pragma unroll
     for (int k = 0; k < 3; ++k) { rg.pa[k] = o.pa[(NCH + k) % 3]; rg.ld[k] = o.ld[(NCH + k) % 3]; }
   }
 
-  // acc = acc * inv + v[feature]   (inv is a power of two: the fma rounds exactly as the add alone would)
-  template <bool RELU>
-  static __device__ __forceinline__ float bias(f32x16 (&acc)[NT], float inv, const float* v, int hh) {
+  // ---- epilogues: accumulators (accumulator file) -> the next layer's input (VGPRs), on packed f32 pairs -----------
+  // One tile at a time: left alone, the scheduler reads all 128 accumulator registers into VGPRs at once — beside the
+  // 128 registers of the input set that is scratch traffic.  Tile t's results and tile t + 1's accumulators pass
+  // through one empty statement, so no read of tile t + 1 is scheduled above the end of tile t.
+  static __device__ __forceinline__ void next_tile(In& in, Acc& acc, int t) {
+    if (t + 1 < NT) asm volatile("" : "+v"(in[4 * t]), "+v"(in[4 * t + 1]), "+v"(in[4 * t + 2]), "+v"(in[4 * t + 3]), "+a"(acc[t + 1]));
+    else asm volatile("" : "+v"(in[4 * t]), "+v"(in[4 * t + 1]), "+v"(in[4 * t + 2]), "+v"(in[4 * t + 3]));
+  }
+
+  // in = ReLU(acc * inv + v[feature]); returns the lane's largest result.  inv is a power of two: the fma rounds exactly
+  // as the add alone would.
+  static __device__ __forceinline__ float bias_relu(In& in, Acc& acc, float inv, const float* v, int hh) {
     float m = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 b = *reinterpret_cast<const float4*>(v + 32 * t + 8 * g + 4 * hh);
-        const float bb[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          float y = __builtin_fmaf(acc[t][4 * g + j], inv, bb[j]);
-          if (RELU) { y = fmaxf(y, 0.f); m = fmaxf(m, y); }
-          acc[t][4 * g + j] = y;
-        }
+        f32x4 y = __builtin_elementwise_fma(HD_GRP(acc[t], g), (f32x4)(inv), hd_lds4(v + 32 * t + 8 * g + 4 * hh));
+        y = __builtin_elementwise_max(y, (f32x4)(0.f));
+        m = hd_max4(m, y);
+        in[4 * t + g] = y;
+        if (g == 3) next_tile(in, acc, t);
       }
     return m;
   }
 
-  // LayerNorm over the H features of every candidate (a candidate's features: the 16 NT registers of lanes r, r+32),
-  // then ReLU; returns the lane's largest result
-  static __device__ __forceinline__ float layer_norm_relu(f32x16 (&acc)[NT], const float* g, const float* b, float eps, int hh) {
-    float s = 0.f;
+  // in = ReLU(LayerNorm(acc * inv + v[feature])) over the H features of every candidate (a candidate's features: the
+  // 16 NT registers of lanes r, r + 32); returns the lane's largest result
+  static __device__ __forceinline__ float bias_ln_relu(In& in, Acc& acc, float inv, const float* v, const float* gm, const float* bt,
+                                                       float eps, int hh) {
+    f32x4 s4 = (f32x4)(0.f);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s += acc[t][i];
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 y = __builtin_elementwise_fma(HD_GRP(acc[t], g), (f32x4)(inv), hd_lds4(v + 32 * t + 8 * g + 4 * hh));
+        s4 += y;
+        in[4 * t + g] = y;
+        if (g == 3) next_tile(in, acc, t);
+      }
+    float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     s += __shfl_xor(s, 32, OCN_WAVE);
-    const float mean = s * (1.0f / (float)H);
-    float q = 0.f;
+    const float nmean = -(s * (1.0f / (float)H));
+    f32x4 q4 = (f32x4)(0.f);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { const float d = acc[t][i] - mean; q += d * d; }
+    for (int t = 0; t < 4 * NT; ++t) {
+      const f32x4 d = in[t] + (f32x4)(nmean);
+      q4 = __builtin_elementwise_fma(d, d, q4);
+      in[t] = d;
+    }
+    float q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
     q += __shfl_xor(q, 32, OCN_WAVE);
     const float rstd = rsqrtf(q * (1.0f / (float)H) + eps);
     float m = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const float4 gg = *reinterpret_cast<const float4*>(g + 32 * t + 8 * gq + 4 * hh);
-        const float4 bb = *reinterpret_cast<const float4*>(b + 32 * t + 8 * gq + 4 * hh);
-        const float ga[4] = {gg.x, gg.y, gg.z, gg.w}, be[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float y = fmaxf((acc[t][4 * gq + j] - mean) * rstd * ga[j] + be[j], 0.f);
-          m = fmaxf(m, y);
-          acc[t][4 * gq + j] = y;
-        }
+      for (int g = 0; g < 4; ++g) {
+        const int fo = 32 * t + 8 * g + 4 * hh;
+        f32x4 y = __builtin_elementwise_fma(in[4 * t + g] * (f32x4)(rstd), hd_lds4(gm + fo), hd_lds4(bt + fo));
+        y = __builtin_elementwise_max(y, (f32x4)(0.f));
+        m = hd_max4(m, y);
+        in[4 * t + g] = y;
       }
     return m;
   }
 
-  static __device__ __forceinline__ float relu_max(f32x16 (&acc)[NT]) {
-    float m = 0.f;
+  // a branch's share acc * inv of the last layer's input goes to this wave's park area (L2-resident) while the next
+  // branch needs the registers: tile t, group g at pk[(4 t + g) * 64] (+ lane)
+  static __device__ __forceinline__ void park_share(f32x4* pk_, Acc& acc, float inv, int lane) {
+    __attribute__((address_space(1))) f32x4* pk = (__attribute__((address_space(1))) f32x4*)pk_;      // (global, not flat)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { acc[t][i] = fmaxf(acc[t][i], 0.f); m = fmaxf(m, acc[t][i]); }
-    return m;
+      for (int g = 0; g < 4; ++g) pk[(4 * t + g) * 64 + lane] = HD_GRP(acc[t], g) * (f32x4)(inv);
+      if (t + 1 < NT) asm volatile("" : "+a"(acc[t + 1]) : : "memory");                  // (tile by tile: see next_tile)
+    }
   }
 };
 
-template <int NT>
+#define HD_PARK_BYTES(H) ((int64_t)HD_MAX_GRID * 4 * 2 * (H) * 32 * 4)
+#define HD_MAX_GRID 256               /* one workgroup per CU (LDS and registers admit no second one): a persistent grid */
+#ifdef OCN_X_HD_STAMPS               /* diagnostic build only (tools/headsbench.py): s_memtime at the phase boundaries of workgroup 0's first tile */
+#define HD_STAMP(k) do { if (blockIdx.x == 0 && tile == 0 && threadIdx.x == 0) \
+    reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.scratch) + HD_PARK_BYTES(H))[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HD_STAMP(k) do {} while (0)
+#endif
+
+template <int NT, bool LN>
 __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsArgs a) {
   using HD = Heads<NT>;
   using Ring = typename HD::Ring;
@@ -337,34 +372,73 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
   const unsigned lane16 = (unsigned)lane * 16u;
   const unsigned lds0 = (unsigned)(size_t)(lds_bytes_t)smem;
   for (int q = threadIdx.x; q < HD::VEC_FLOATS; q += OCN_BLOCK) s_vec[q] = a.vec[q];
-  // where this wave parks a finished branch's share of the output while the next branch needs the registers
-  float4* park = reinterpret_cast<float4*>(a.scratch) + ((size_t)(blockIdx.x * 4 + w) * 2) * (NT * 4) * 64 + lane;
   const i64 n_tiles = a.dump ? 1 : (a.B + HD_ROWS - 1) / HD_ROWS;
 #ifdef OCN_X_HD_CLOCK                /* diagnostic build only: the clock the chip holds under this kernel (guide, DVFS give-back item 6) */
   const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
+  // class boundaries of the class-major order (both | cn1 only | cn2 only | none), or "every row runs every branch"
+  i64 m3 = a.B, m32 = a.B, m321 = a.B;
+  if (a.ranges) { m3 = a.ranges[2 * 1 + 1]; m32 = a.ranges[2 * 0 + 1]; m321 = a.ranges[2 * 3 + 1]; }
+  // which branches a tile runs follows from the boundaries alone; branch 0 = xcn1lin, 1 = xcn2lin, 2 = xijlin
+  auto tile_runs = [&](i64 tl, int br) -> bool {
+    const i64 lo = tl * HD_ROWS, hi = lo + HD_ROWS < a.B ? lo + HD_ROWS : a.B;
+    if (br == 0) return lo < m32;
+    if (br == 1) return a.b_on_union ? lo < m321 : (lo < m3 || (lo > m32 ? lo : m32) < (hi < m321 ? hi : m321));
+    return true;
+  };
+  auto row_has = [&](i64 slot, int br) -> bool {          // does this candidate's pooled input of branch br exist
+    if (slot >= a.B) return false;
+    if (br == 0) return slot < m32;
+    if (br == 1) return a.b_on_union ? slot < m321 : (slot < m3 || (slot >= m32 && slot < m321));
+    return true;
+  };
+  auto x_row = [&](i64 tl, int br) -> const float* {      // the lane's input row of branch br in tile tl (+ 4 hh floats)
+    const i64 slot = tl * HD_ROWS + 32 * w + r;
+    return a.x[br] + (slot < a.B ? slot : a.B - 1) * a.ldx + 4 * hh;
+  };
+  auto first_branch = [&](i64 tl) -> int { return tile_runs(tl, 0) ? 0 : (tile_runs(tl, 1) ? 1 : 2); };
+
   // uniform pointers as scalar pairs (the "s" operands of hd_dma)
   auto uni = [](const char* p) -> const char* {
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (const char*)(((unsigned long long)hi << 32) | lo);
   };
+  typename HD::In rA;                // the running layer's input (VGPRs)
+  typename HD::Acc rB;               // its output (accumulator file)
+  // where this wave parks the pooled branches' shares of the last layer's input
+  // (a uniform base and a lane index: scalar-base addressing, no per-tile address registers)
+  f32x4* park = reinterpret_cast<f32x4*>(const_cast<char*>(uni(reinterpret_cast<const char*>(
+      reinterpret_cast<f32x4*>(a.scratch) + ((size_t)(blockIdx.x * 4 + w) * 2) * (NT * 4) * 64))));
+  // the first tile's first input rows; every later first layer finds its rows prefetched by the layer before it
+  {
+    const float* xr = x_row(blockIdx.x, first_branch(blockIdx.x));
+    hd_unroll<4 * NT>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      hd_xload<(32 * (i / 4) + 8 * (i % 4)) * 4>(rA[i], xr);
+    });
+    HD::xwait(rA);
+  }
+  // rows without a pooled input count as zero rows (the pooling never wrote them); returns the lane's largest |x|
+  auto x_prepare = [&](bool has) -> float {
+    float m = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4 * NT; ++t) {
+      rA[t] = has ? rA[t] : (f32x4)(0.f);
+      m = hd_max4(m, __builtin_elementwise_abs(rA[t]));
+    }
+    HD::pin_in(rA);
+    return m;
+  };
 
 #pragma unroll 1
   for (i64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const i64 slot = tile * HD_ROWS + 32 * w + r;
     const bool live = slot < a.B;
-    const i64 arow = live ? slot : a.B - 1;
-    // class of this candidate (class-major order: both | cn1 only | cn2 only | none)
-    bool has1 = live, hasB = live;
-    if (a.ranges) {
-      const i64 m3 = a.ranges[2 * 1 + 1], m32 = a.ranges[2 * 0 + 1], m321 = a.ranges[2 * 3 + 1];
-      has1 = live && slot < m32;
-      const bool has2 = slot < m3 || (slot >= m32 && slot < m321);
-      hasB = live && (a.b_on_union ? slot < m321 : has2);
-    }
-    // (the barriers also mean: s_vec is written, and nobody reads the previous tile's ring slots any more)
-    const int wgA = __syncthreads_or(has1), wgB = __syncthreads_or(hasB);
+    const int wgA = tile_runs(tile, 0), wgB = tile_runs(tile, 1);
+    const i64 ntile = tile + gridDim.x < n_tiles ? tile + gridDim.x : tile;       // (past the end: this tile's rows once more)
+    __syncthreads();                  // s_vec is written; nobody reads the previous tile's ring slots any more
+    HD_STAMP(0);
 
     Ring rg;
 #pragma unroll
@@ -381,30 +455,9 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
         for (int q = 0; q < NPW; ++q) hd_dma(lane16, p0 + (size_t)k * CHB + (size_t)q * 4096, rg.ld[k] + q * 4096);
       hd_sync<NPW>();                                                          // chunk 0 is there, chunk 1 on its way
     }
+    HD_STAMP(1);
 
-    f32x16 rA[NT], rB[NT];            // rA lives in VGPRs, rB in the accumulator file
-    // the raw input rows of a branch, in accumulator layout; rows the pooling never wrote count as zero rows
-    auto load_x = [&](const float* xb, bool rowmask) -> float {
-      const float* xrow = xb + arow * a.ldx + 4 * hh;
-      float m = 0.f;
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 v = *reinterpret_cast<const float4*>(xrow + 32 * t + 8 * g);
-          const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float y = rowmask ? vv[j] : 0.f;
-            m = fmaxf(m, fabsf(y));
-            rB[t][4 * g + j] = y;
-          }
-        }
-      HD::pin_a(rB);
-      return m;
-    };
-
-    // ---- pooled branches a (xcn1lin) and b (xcn2lin): their share M . act of the output is parked in memory ------
+    // ---- pooled branches a (xcn1lin) and b (xcn2lin): their shares M . act of the last layer's input -------------
 #pragma unroll 1
     for (int br = 0; br < 2; ++br) {
       if (!(br == 0 ? wgA : wgB)) continue;
@@ -412,92 +465,136 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
       const char* p0 = uni(a.panel[3 * br]) + (size_t)w * 1024;
       const char* p1 = uni(a.panel[3 * br + 1]) + (size_t)w * 1024;
       const char* p2 = uni(a.panel[3 * br + 2]) + (size_t)w * 1024;
-      const char* pn = uni(a.panel[(br == 0 && wgB) ? P_B0 : P_X0]) + (size_t)w * 1024;
+      const int nbr = (br == 0 && wgB) ? 1 : 2;                               // the branch whose rows the third layer prefetches
+      const char* pn = uni(a.panel[3 * nbr]) + (size_t)w * 1024;
       float sc, inv;
-      hd_row_scale(load_x(br == 0 ? a.x[0] : a.x[1], br == 0 ? has1 : hasB), s_scal[1 + 3 * br], sc, inv);
-      HD::template layer<false, true, false>(rA, rB, sc, rg, p0, p1, lane16);
-      float m = HD::template bias<true>(rA, inv, vb, hh);
-      HD::pin_v(rA);
+      hd_row_scale(x_prepare(row_has(slot, br)), s_scal[1 + 3 * br], sc, inv);
+      HD_STAMP(2 + 7 * br);
+      HD::template layer<false, false>(rB, rA, sc, rg, p0, p1, lane16, nullptr);
+      HD_STAMP(3 + 7 * br);
+      float m = HD::bias_relu(rA, rB, inv, vb, hh);
+      HD::pin_in(rA);
       hd_row_scale(m, s_scal[2 + 3 * br], sc, inv);
-      HD::template layer<true, false, false>(rB, rA, sc, rg, p1, p2, lane16);
-      m = HD::template bias<false>(rB, inv, vb + H, hh);
-      m = a.ln ? HD::layer_norm_relu(rB, vb + 2 * H, vb + 3 * H, a.eps, hh) : HD::relu_max(rB);
-      HD::pin_a(rB);
+      HD_STAMP(4 + 7 * br);
+      HD::template layer<false, false>(rB, rA, sc, rg, p1, p2, lane16, nullptr);
+      HD_STAMP(5 + 7 * br);
+      if constexpr (LN) m = HD::bias_ln_relu(rA, rB, inv, vb + H, vb + 2 * H, vb + 3 * H, a.eps, hh);
+      else m = HD::bias_relu(rA, rB, inv, vb + H, hh);
+      HD::pin_in(rA);
       hd_row_scale(m, s_scal[3 + 3 * br], sc, inv);
-      HD::template layer<false, true, false>(rA, rB, sc, rg, p2, pn, lane16);
-      float4* pk = park + (size_t)br * (NT * 4) * 64;
-      asm volatile("" : "+v"(pk));           // (or every one of the 2 x 4 NT addresses is precomputed outside the tile loop and kept)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) rA[t][i] *= inv;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          pk[g * 64] = make_float4(rA[t][4 * g], rA[t][4 * g + 1], rA[t][4 * g + 2], rA[t][4 * g + 3]);
-        pk += 4 * 64;
-        asm volatile("" : "+v"(pk));
-      }
-      if (a.dump && w == 0 && r == 0) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) a.dump[br * H + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh] = rA[t][i];
-      }
+      HD_STAMP(6 + 7 * br);
+      HD::template layer<false, true>(rB, rA, sc, rg, p2, pn, lane16, x_row(tile, nbr));
+      HD_STAMP(7 + 7 * br);
+      // (constants mode: B = 1, every lane holds row 0 — wave 0's share, as parked, IS the constant in the park layout)
+      HD::park_share((a.dump && w == 0 ? reinterpret_cast<f32x4*>(a.dump) : park) + (size_t)br * (NT * 4) * 64, rB, inv, lane);
+      HD_STAMP(8 + 7 * br);
     }
-    // ---- xijlin ---------------------------------------------------------------------------------------------
+    // ---- xijlin, then out = ((share a + share b) + share c) + folded bias ---------------------------------------
+    float inv;
     {
       const char* px = uni(a.panel[P_X0]) + (size_t)w * 1024;
       const char* pc = uni(a.panel[P_MC]) + (size_t)w * 1024;
-      float sc, inv;
-      hd_row_scale(load_x(a.x[2], live), s_scal[1 + P_X0], sc, inv);
-      HD::template layer<false, true, false>(rA, rB, sc, rg, px, pc, lane16);
-      float m = HD::template bias<false>(rA, inv, s_vec + V_B0X * H, hh);
-      m = a.ln ? HD::layer_norm_relu(rA, s_vec + V_GX * H, s_vec + V_EX * H, a.eps, hh) : HD::relu_max(rA);
-      HD::pin_v(rA);
+      float sc;
+      hd_row_scale(x_prepare(live), s_scal[1 + P_X0], sc, inv);
+      HD_STAMP(16);
+      HD::template layer<false, false>(rB, rA, sc, rg, px, pc, lane16, nullptr);
+      HD_STAMP(17);
+      float m;
+      if constexpr (LN) m = HD::bias_ln_relu(rA, rB, inv, s_vec + V_B0X * H, s_vec + V_GX * H, s_vec + V_EX * H, a.eps, hh);
+      else m = HD::bias_relu(rA, rB, inv, s_vec + V_B0X * H, hh);
+      HD::pin_in(rA);
       hd_row_scale(m, s_scal[1 + P_MC], sc, inv);
-      HD::template layer<true, false, true>(rB, rA, sc, rg, pc, pc, lane16);
-      // ---- out = ((share a + share b) + share c) + folded bias; a skipped branch's share is its constant -------
-      const float4* pa = park;
-      const float4* pb = park + (size_t)(NT * 4) * 64;
+      HD_STAMP(18);
+      HD::template layer<true, true>(rB, rA, sc, rg, pc, pc, lane16, x_row(ntile, first_branch(ntile)));
+      HD_STAMP(19);
+    }
+    // ---- lin: LayerNorm, ReLU, Linear(H, 1) on the accumulator file (the VGPR set already holds the next rows) -----
+    f32x4 s4 = (f32x4)(0.f);
+    {
+      // ((share a + share b) + share c) + folded bias; a skipped branch's share is its constant.  The parked shares of
+      // tile t + 1 are requested before tile t is combined.
+      typedef const __attribute__((address_space(1))) f32x4* gf4_t;          // (global, not flat: flat loads count out of order)
+      gf4_t pk = (gf4_t)park;
+      asm volatile("" : "+s"(pk));          // (opaque per tile: or the 64 load addresses are hoisted out of the tile loop and spilled)
+      // (the constants come in the park layout too: both cases are global loads from a uniform base)
+      gf4_t ck = (gf4_t)reinterpret_cast<const f32x4*>(a.cpark);
+      asm volatile("" : "+s"(ck));
+      gf4_t pa = wgA ? pk : ck;
+      gf4_t pb = (wgB ? pk : ck) + (size_t)(NT * 4) * 64;
+      f32x4 na[4], nb[4];
+      auto fetch = [&](int t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          na[g] = pa[(4 * t + g) * 64 + lane];
+          nb[g] = pb[(4 * t + g) * 64 + lane];
+        }
+      };
+      fetch(0);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        asm volatile("" : "+v"(pa), "+v"(pb));               // a tile at a time: addresses and values of all tiles at once is 400 registers
+        f32x4 ca[4], cb[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { ca[g] = na[g]; cb[g] = nb[g]; }
+        if (t + 1 < NT) fetch(t + 1);
+        f32x16 o;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 v = ((ca[g] + cb[g]) + HD_GRP(rB[t], g) * (f32x4)(inv)) + hd_lds4(s_vec + V_BF * H + 32 * t + 8 * g + 4 * hh);
+          s4 += v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[4 * g + j] = v[j];
+        }
+        rB[t] = o;
+        if (t + 1 < NT) asm volatile("" : "+a"(rB[t]), "+a"(rB[t + 1]));
+        else asm volatile("" : "+a"(rB[t]));
+      }
+    }
+    float d = 0.f;
+    const float* dw = s_vec + V_DOTW * H;
+    if constexpr (LN) {
+      float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+      s += __shfl_xor(s, 32, OCN_WAVE);
+      const float nmean = -(s * (1.0f / (float)H));
+      f32x4 q4 = (f32x4)(0.f);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 dd = HD_GRP(rB[t], g) + (f32x4)(nmean);
+          q4 = __builtin_elementwise_fma(dd, dd, q4);
+        }
+      float q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
+      q += __shfl_xor(q, 32, OCN_WAVE);
+      const float rstd = rsqrtf(q * (1.0f / (float)H) + a.eps);
+      f32x4 d4 = (f32x4)(0.f);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int fo = 32 * t + 8 * g + 4 * hh;
-          const float4 sa = wgA ? pa[g * 64] : *reinterpret_cast<const float4*>(s_vec + V_CA * H + fo);
-          const float4 sb = wgB ? pb[g * 64] : *reinterpret_cast<const float4*>(s_vec + V_CB * H + fo);
-          const float4 bf = *reinterpret_cast<const float4*>(s_vec + V_BF * H + fo);
-          rB[t][4 * g + 0] = ((sa.x + sb.x) + rB[t][4 * g + 0] * inv) + bf.x;
-          rB[t][4 * g + 1] = ((sa.y + sb.y) + rB[t][4 * g + 1] * inv) + bf.y;
-          rB[t][4 * g + 2] = ((sa.z + sb.z) + rB[t][4 * g + 2] * inv) + bf.z;
-          rB[t][4 * g + 3] = ((sa.w + sb.w) + rB[t][4 * g + 3] * inv) + bf.w;
+          f32x4 y = __builtin_elementwise_fma((HD_GRP(rB[t], g) + (f32x4)(nmean)) * (f32x4)(rstd), hd_lds4(s_vec + V_GL * H + fo),
+                                              hd_lds4(s_vec + V_EL * H + fo));
+          y = __builtin_elementwise_max(y, (f32x4)(0.f));
+          d4 = __builtin_elementwise_fma(y, hd_lds4(dw + fo), d4);
         }
-        asm volatile("" : "+a"(rB[t]));
-        pa += 4 * 64;
-        pb += 4 * 64;
-      }
+      d = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+    } else {
+      f32x4 d4 = (f32x4)(0.f);
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          d4 = __builtin_elementwise_fma(__builtin_elementwise_max(HD_GRP(rB[t], g), (f32x4)(0.f)), hd_lds4(dw + 32 * t + 8 * g + 4 * hh), d4);
+      d = (d4[0] + d4[1]) + (d4[2] + d4[3]);
     }
-    // ---- lin: LayerNorm, ReLU, Linear(H, 1) -------------------------------------------------------------------
-    if (a.ln) HD::layer_norm_relu(rB, s_vec + V_GL * H, s_vec + V_EL * H, a.eps, hh);
-    else HD::relu_max(rB);
-    float d = 0.f;
-    const float* dw = s_vec + V_DOTW * H;
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const float4 ww = *reinterpret_cast<const float4*>(dw + 32 * t + 8 * gq + 4 * hh);
-        d += rB[t][4 * gq + 0] * ww.x + rB[t][4 * gq + 1] * ww.y + rB[t][4 * gq + 2] * ww.z + rB[t][4 * gq + 3] * ww.w;
-      }
     d += __shfl_xor(d, 32, OCN_WAVE);
     if (live && hh == 0 && !a.dump) a.y[a.y_row_map ? a.y_row_map[slot] : slot] = d + s_scal[0];
+    HD_STAMP(20);
   }
 #ifdef OCN_X_HD_CLOCK
-  if (threadIdx.x == 0) {            // into this workgroup's own (now dead) park area: nothing reads it
-    unsigned long long* o = reinterpret_cast<unsigned long long*>(reinterpret_cast<float4*>(a.scratch) + ((size_t)(blockIdx.x * 4) * 2) * (NT * 4) * 64);
-    o[0] = __builtin_amdgcn_s_memtime() - clk0;
-    o[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  if (threadIdx.x == 0) {            // into the scratch page of the diagnostic builds
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.scratch) + HD_PARK_BYTES(H)) + 64 + 2 * blockIdx.x;
+    if (blockIdx.x < 192) { o[0] = __builtin_amdgcn_s_memtime() - clk0; o[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
   }
 #endif
 }
@@ -528,19 +625,18 @@ __global__ __launch_bounds__(OCN_BLOCK) void split_weight_f16_kernel(const float
   }
 }
 
-#define HD_MAX_GRID 256               /* one workgroup per CU (LDS and registers admit no second one): a persistent grid */
-template <int NT>
+template <int NT, bool LN>
 static int heads_launch(const HeadsArgs& a, i64 tiles, hipStream_t st) {
   static bool raised_dev[64] = {};
   int devid = 0;
   if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return OCN_EINVAL;
   if (!raised_dev[devid]) {
-    const hipError_t e = hipFuncSetAttribute((const void*)heads_fused_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    const hipError_t e = hipFuncSetAttribute((const void*)heads_fused_kernel<NT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)Heads<NT>::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     raised_dev[devid] = true;
   }
-  hipLaunchKernelGGL((heads_fused_kernel<NT>), dim3((unsigned)(tiles < HD_MAX_GRID ? tiles : HD_MAX_GRID)), dim3(OCN_BLOCK),
+  hipLaunchKernelGGL((heads_fused_kernel<NT, LN>), dim3((unsigned)(tiles < HD_MAX_GRID ? tiles : HD_MAX_GRID)), dim3(OCN_BLOCK),
                      Heads<NT>::LDS_BYTES, st, a);
   return launch_status();
 }
@@ -563,7 +659,9 @@ int ocn_heads_split_weight(const float* W, int32_t N, int32_t K, float scale, vo
 int32_t ocn_heads_nvec(void) { return HD_NVEC; }
 int32_t ocn_heads_nscal(void) { return HD_NSCAL; }
 
-int64_t ocn_heads_scratch_bytes(int32_t H) { return (int64_t)HD_MAX_GRID * 4 * 2 * H * 32 * 4; }
+int64_t ocn_heads_const_bytes(int32_t H) { return (int64_t)2 * H * 32 * 4; }   /* two shares of one wave, park layout */
+
+int64_t ocn_heads_scratch_bytes(int32_t H) { return HD_PARK_BYTES(H) + 4096; }   /* + a page of diagnostic stamps */
 
 int ocn_heads_fused(const OcnHeadsArgs* h, void* stream) {
   if (!h || h->B < 0 || h->H <= 0) return OCN_EINVAL;
@@ -571,6 +669,7 @@ int ocn_heads_fused(const OcnHeadsArgs* h, void* stream) {
   for (int i = 0; i < 3; ++i)
     if (!h->x[i] || !h->p_first[i] || !h->p_out[i]) return OCN_EINVAL;
   if (!h->p_mid[0] || !h->p_mid[1] || !h->vec || !h->scratch || (!h->y && !h->dump)) return OCN_EINVAL;
+  if (h->dump ? h->B != 1 : !h->cpark) return OCN_EINVAL;
   const int64_t ldx = h->ldx ? h->ldx : h->H;
   if (ldx < h->H || (ldx & 3)) return OCN_EINVAL;
   HeadsArgs a;
@@ -579,12 +678,12 @@ int ocn_heads_fused(const OcnHeadsArgs* h, void* stream) {
   a.panel[P_B0] = (const char*)h->p_first[1]; a.panel[P_B3] = (const char*)h->p_mid[1]; a.panel[P_MB] = (const char*)h->p_out[1];
   a.panel[P_X0] = (const char*)h->p_first[2]; a.panel[P_MC] = (const char*)h->p_out[2];
   a.ldx = ldx; a.B = h->B; a.vec = h->vec; a.ranges = (const i64*)h->ranges; a.y_row_map = (const i64*)h->y_row_map;
-  a.y = h->y; a.dump = h->dump; a.scratch = h->scratch; a.eps = h->eps; a.ln = h->ln; a.b_on_union = h->b_on_union;
+  a.y = h->y; a.dump = h->dump; a.cpark = h->cpark; a.scratch = h->scratch; a.eps = h->eps; a.ln = h->ln; a.b_on_union = h->b_on_union;
   const i64 tiles = h->dump ? 1 : (h->B + HD_ROWS - 1) / HD_ROWS;
   hipStream_t st = (hipStream_t)stream;
   switch (h->H) {
-    case 128: return heads_launch<4>(a, tiles, st);
-    case 256: return heads_launch<8>(a, tiles, st);
+    case 128: return h->ln ? heads_launch<4, true>(a, tiles, st) : heads_launch<4, false>(a, tiles, st);
+    case 256: return h->ln ? heads_launch<8, true>(a, tiles, st) : heads_launch<8, false>(a, tiles, st);
     default: return OCN_EINVAL;
   }
 }

@@ -851,14 +851,12 @@ class _CNPredictorBase(nn.Module):
                         out=[pans[2][0], pans[5][0], pans[7][0]],
                         vec=vec, ln=ln, eps=(sa[1][1].eps if ln else 1e-5), flops_per_row=2.0 * H * H * 8)
             # the constants a skipped branch contributes: the branch's share of the output on an all-zero pooled row,
-            # computed by the kernel itself (dump mode) so that skipping changes no bit
+            # computed by the kernel itself (constants mode) so that skipping changes no bit
             z = torch.zeros(1, H, device=dev)
-            dump = torch.empty(2, H, device=dev)
+            cpark = torch.empty(int(ops._lib.lib().ocn_heads_const_bytes(H)) // 4, device=dev)
             scratch = ops.buf(self._ws, "heads_scratch", int(ops._lib.lib().ocn_heads_scratch_bytes(H)) // 4, torch.float32, dev)
-            ops.heads_fused(z, z, z, pack, None, None, self._xcn2_on_union, scratch, dump=dump)
-            nv = len(vecs)
-            vec[(nv - 2) * H:(nv - 1) * H] = dump[0]
-            vec[(nv - 1) * H:nv * H] = dump[1]
+            ops.heads_fused(z, z, z, pack, None, None, self._xcn2_on_union, scratch, dump=cpark)
+            pack["cpark"] = cpark
         self._fpack, self._fpack_key = pack, key
         return pack
 

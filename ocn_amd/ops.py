@@ -701,7 +701,8 @@ fused_heads_min_width = 128      # narrower heads (ppa / citation2 / ddi: H = 32
 def heads_fused(x1: Tensor, x2: Tensor, xij: Tensor, pack: dict, ranges: Optional[Tensor], y_row_map: Optional[Tensor],
                 b_on_union: bool, scratch: Tensor, dump: Optional[Tensor] = None) -> Optional[Tensor]:
     """ocn_hip.h: ocn_heads_fused.  ``pack``: panels / vectors prepared by ``model._CNPredictorBase._fused_pack``.
-    Returns the [B, 1] scores (or None in dump mode, where ``dump`` [2, H] receives the branch constants)."""
+    Returns the [B, 1] scores (or None in constants mode, where ``dump`` receives what a skipped branch contributes;
+    scoring mode reads it back as ``pack["cpark"]``)."""
     for t, nm in ((x1, "xcn1"), (x2, "xcn2"), (xij, "xij")):
         _req(t, torch.float32, nm, 2)
     B, H = xij.shape
@@ -718,11 +719,17 @@ def heads_fused(x1: Tensor, x2: Tensor, xij: Tensor, pack: dict, ranges: Optiona
     a.ranges = 0 if ranges is None else _req(ranges, torch.int64, "ranges").data_ptr()
     a.y_row_map = 0 if y_row_map is None else _req(y_row_map, torch.int64, "y_row_map", 1).data_ptr()
     y = None
+    nconst = int(_lib.lib().ocn_heads_const_bytes(H)) // 4
     if dump is None:
         y = torch.empty((B, 1), dtype=torch.float32, device=xij.device)
         a.y = y.data_ptr()
+        if _req(pack["cpark"], torch.float32, "cpark", 1).numel() != nconst:
+            raise ValueError("heads_fused: constants buffer of the wrong size")
+        a.cpark = pack["cpark"].data_ptr()
     else:
-        a.dump = _req(dump, torch.float32, "dump", 2).data_ptr()
+        if B != 1 or _req(dump, torch.float32, "dump", 1).numel() != nconst:
+            raise ValueError("heads_fused: constants mode takes one row and ocn_heads_const_bytes(H) bytes")
+        a.dump = dump.data_ptr()
     if scratch.numel() * scratch.element_size() < int(_lib.lib().ocn_heads_scratch_bytes(H)):
         raise ValueError("heads_fused: scratch too small")
     a.scratch = scratch.data_ptr()

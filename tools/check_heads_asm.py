@@ -1,8 +1,9 @@
 """Audit of the heads kernel's ISA (cdna_hip_programming.md §5.7: the compiler neither counts the memory operations of an
 asm statement nor pads its hazards).  Compiles ocn_amd/csrc/heads.hip to assembly and checks, for every heads_fused_kernel:
 
-  1. no instruction reads or writes the destination of a ds_read_b128 that the counted s_waitcnt lgkmcnt(N) ladder has
-     not yet retired (a compiler copy / spill of an in-flight fragment register would be silent corruption);
+  1. no instruction reads or writes the destination of a ds_read_b128 / global_load that the counted s_waitcnt
+     lgkmcnt(N) / vmcnt(N) ladders have not yet retired (a compiler copy / spill of an in-flight register would be silent
+     corruption);
   2. no VALU result is an MFMA A/B operand within the next 2 wait states;
   3. no non-MFMA instruction touches an MFMA's result within 12 wait states;
   4. no scratch (private memory) access.
@@ -62,6 +63,7 @@ def audit(path):
                 name = None
     for fn, lines in funcs.items():
         inflight = []                      # destinations of outstanding ds_reads, oldest first (None: compiler's own LDS op)
+        vm = []                            # the same for vector-memory operations (loads, stores, LDS-DMA count together)
         recent = []                        # (wait states ago, kind, written regs) of the last instructions
         n_mfma = n_read = 0
         for ln, line in enumerate(lines):
@@ -72,7 +74,7 @@ def audit(path):
                 problems.append(f"{fn}:{ln}: scratch access: {line.strip()}")
             touched = regs(" ".join(ops))
             written = regs(ops[0]) if ops and not op.startswith(("ds_write", "global_store", "s_", "global_load_lds", "ds_read")) else set()
-            if op.startswith("ds_read"):
+            if op.startswith(("ds_read", "global_load_dword")):
                 written = regs(ops[0])
             # 1. in-flight LDS destinations
             if op == "s_waitcnt":
@@ -81,11 +83,26 @@ def audit(path):
                     keep = int(m.group(1))
                     while len(inflight) > keep:
                         inflight.pop(0)
+                m = re.search(r"vmcnt\((\d+)\)", line)
+                if m:
+                    keep = int(m.group(1))
+                    while len(vm) > keep:
+                        vm.pop(0)
             else:
                 for dst in inflight:
                     if dst and dst & touched:
                         problems.append(f"{fn}:{ln}: touches an in-flight LDS destination: {line.strip()}")
                         break
+                for dst in vm:
+                    if dst and dst & touched:
+                        problems.append(f"{fn}:{ln}: touches an in-flight global-load destination: {line.strip()}")
+                        break
+            if op.startswith(("global_load_lds", "global_store", "global_atomic", "scratch_store", "buffer_store")):
+                vm.append(None)
+            elif op.startswith(("global_load", "scratch_load", "buffer_load")):
+                vm.append(regs(ops[0]))
+            elif op.startswith("flat_"):
+                problems.append(f"{fn}:{ln}: flat access (out-of-order counters): {line.strip()}")
             if op.startswith("ds_read"):
                 inflight.append(regs(ops[0]))
                 n_read += 1

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 i=0
 for g in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES" \
          "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS" \
-         "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+         "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQC_ICACHE_MISSES SQC_ICACHE_HITS SQC_ICACHE_REQ SQ_IFETCH SQC_ICACHE_MISSES_DUPLICATE SQC_TC_INST_REQ"; do
   rm -rf $O/${T}_hpmc_$i
   HB_N=6 timeout -k 10 300 rocprofv3 --pmc $g --kernel-trace -d $O/${T}_hpmc_$i -o run --output-format csv -- python3 tools/headsbench.py > $O/${T}_hpmc_$i.out 2> $O/${T}_hpmc_$i.err || echo "pass $i failed"
   i=$((i+1))

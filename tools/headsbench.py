@@ -39,4 +39,10 @@ for H, B in ((256, 65536), (128, 32768)):
         st = sc.view(torch.int64).view(-1, per)[:, :2].double()
         ghz = (st[:, 0] / st[:, 1] * 0.1).median().item()
         print(f"in-kernel clock {ghz:.2f} GHz; kernel cycles (median WG) {st[:, 0].median().item():.0f}", flush=True)
+    if "-DOCN_X_HD_STAMPS" in flags:       # s_memtime at the phase boundaries of workgroup 0's first tile (heads.hip: HD_STAMP)
+        sc = [v for v in pred._ws.values() if torch.is_tensor(v) and v.numel() * 4 == int(_lib.lib().ocn_heads_scratch_bytes(H))][0]
+        st = sc.view(torch.int64)[-512:][:21].cpu().tolist()
+        names = ["ring prologue"] + [f"{b}.{p}" for b in "ab" for p in ("load x", "L0", "epi0", "L3", "epi3 LN", "L7", "park")] + ["c.load x", "c.L0", "c.epi LN", "c.Lout", "final"]
+        print("  ".join(f"{n} {st[i + 1] - st[i]}" for i, n in enumerate(names)), flush=True)
+        print(f"tile cycles {st[20] - st[0]}", flush=True)
     print(f"{' '.join(flags) or 'product':28s} H={H} B={B}: {dt * 1e6:8.1f} us  {fl / dt / 1e12:6.1f} TF f32-equivalent  {6 * fl / dt / 1e15:5.2f} PF bf16 issued", flush=True)
