@@ -515,11 +515,13 @@ def main():
                 stages[k]["compulsory_GBps"] = roofs[k]["achieved"]
             dom = max((k for k in ("cn_flags", "cn_gather", "linear") if k in stages), key=lambda k: per_step[k])
             roof_hbm = roofs.get("cn_gather")
-            if dom == "linear":
-                # MFMA work of the MLP heads per launch.  The fused kernel (ocn_heads_fused) multiplies a row by 8
-                # H x H panels (the reference's 9 Linear(H,H): the last layer of each branch is folded into lin's
-                # Linear offline, model._fused_pack) and skips, per 128-row tile of the class-major order, the pooled
-                # branches whose input is all zero; every f32 product is six bf16 MFMA cross terms.
+            if "linear" in stages:
+                # MFMA work of the MLP heads per launch.  The fused kernel (ocn_heads_fused, H >= 128) multiplies a row by
+                # 8 H x H panels (the reference's 9 Linear(H,H): the last layer of each branch is folded into lin's Linear
+                # offline, model._fused_pack), skips, per 128-row tile of the class-major order, the pooled branches whose
+                # input is all zero, and evaluates every f32 product as THREE f16 MFMAs (hi/lo splits of both operands).
+                # The grouped Linear launches (narrower heads) issue six bf16 MFMAs per product.  frac is the fraction of
+                # the pipe the kernel runs on: issued f16 / bf16 MFMA FLOPs over the dense 16-bit MFMA peak.
                 launches_per_step = stages["linear"]["launches"] / sampled
                 Bm = mines[0].shape[1]
                 t = stages["linear"]["ms"] * 1e-3
@@ -532,7 +534,7 @@ def main():
                 if fused:
                     rows_a, rows_b = (n_cn1, n_b) if skipping else (Bm, Bm)
                     f32_fl = 2.0 * H * H * (3 * rows_a + 3 * rows_b + 2 * Bm) / launches_per_step
-                    kern = "heads_fused_kernel"
+                    kern, terms, pipe = "heads_fused_kernel", 3, "f16"
                 else:
                     f32_fl = ref_fl
                     if skipping and pred._heads_plan(H) is not None:
@@ -540,23 +542,22 @@ def main():
                         lin_layers = sum(1 for m in pred.lin if isinstance(m, torch.nn.Linear) and m.out_features == H)
                         f32_fl = (2.0 * H * H * (2 * n_cn1 + 2 * n_b + sx_layers * Bm + lin_layers * Bm)
                                   + 2.0 * (2 * H) * H * n_any) / launches_per_step
-                    kern = "linear_bf16x6_kernel"
-                roof = dict(bound="mfma", kernel=kern, achieved=f32_fl / t / 1e12, peak=F32_MFMA_PEAK / 1e12,
-                            unit="TFLOP/s", frac=f32_fl / t / F32_MFMA_PEAK, traffic=pmc(kern),
-                            algorithmic_flops_per_launch=f32_fl, avg_launch_ms=stages["linear"]["ms"],
-                            launches_per_step=launches_per_step,
-                            executed_bf16_tflops=6 * f32_fl / t / 1e12, bf16_mfma_peak_tflops=BF16_MFMA_PEAK / 1e12,
-                            executed_frac_of_bf16_peak=6 * f32_fl / t / BF16_MFMA_PEAK,
-                            reference_head_f32_flops_per_step=2.0 * H * H * 9 * Bm + 2.0 * H * Bm,
-                            skipped_zero_rows=skipping,
-                            note="dtype f32: achieved / peak / frac = the f32 FLOPs the launch executes (2*H*H per row and "
-                                 "panel, rows of skipped all-zero branches excluded, the 9 Linear(H,H) of the reference "
-                                 "folded to 8 panels) against the dense f32 MFMA peak.  The kernel evaluates every f32 product "
-                                 "as six bf16 MFMA cross terms (bf16x6 split): executed_bf16_tflops = 6x that, against the dense "
-                                 "bf16 peak in executed_frac_of_bf16_peak — the pipe it actually runs on.  Head: "
-                                 + head_layout(pred))
-            else:
-                roof = roofs[dom]
+                    kern, terms, pipe = "linear_bf16x6_kernel", 6, "bf16"
+                issued = terms * f32_fl
+                roofs["heads"] = dict(bound="mfma", kernel=kern, achieved=issued / t / 1e12, peak=BF16_MFMA_PEAK / 1e12,
+                                      unit="TFLOP/s", frac=issued / t / BF16_MFMA_PEAK, traffic=pmc(kern),
+                                      algorithmic_flops_per_launch=issued, avg_launch_ms=stages["linear"]["ms"],
+                                      launches_per_step=launches_per_step, mfma_per_f32_product=terms, mfma_dtype=pipe,
+                                      f32_equivalent_tflops=f32_fl / t / 1e12, f32_equivalent_flops_per_launch=f32_fl,
+                                      f32_equivalent_frac_of_f32_mfma_peak=f32_fl / t / F32_MFMA_PEAK,
+                                      reference_head_f32_flops_per_step=2.0 * H * H * 9 * Bm + 2.0 * H * Bm,
+                                      skipped_zero_rows=skipping,
+                                      note=f"achieved / peak / frac = the {pipe} MFMA FLOPs the launch issues ({terms} MFMAs per f32 "
+                                           "product; 2*H*H per row and panel, rows of skipped all-zero branches excluded, the 9 "
+                                           "Linear(H,H) of the reference folded to 8 panels) against the dense 16-bit MFMA peak; "
+                                           "f32_equivalent_* = the same work counted once per f32 product.  MFMA-busy counters: "
+                                           "profiles/r03_heads_pmc.json.  Head: " + head_layout(pred))
+            roof = roofs["heads"] if dom == "linear" else roofs[dom]
         cpu, err, ref_scale = None, None, None
         if world == 1 and not args.no_cpu_baseline:
             cpu, b, ref = cpu_baseline(wl, args, mines[0])

@@ -79,47 +79,88 @@ __device__ __forceinline__ void hd_unroll(F&& f) { hd_unroll_impl(f, std::make_i
 // operations of an asm statement nor pads its hazards; every wait below is counted by hand, see Heads::layer; the
 // ISA is audited by tools/check_heads_asm.py) --------------------------------------------------------------------
 
-// acc (+)= A . B after at most N LDS reads are still outstanding (N < 0: no wait); CZ: the accumulator starts at 0.
-// The accumulators live in the accumulator file ("a").
-template <bool CZ, int N>
-__device__ __forceinline__ void hd_mfma(f32x16& c, const h16x8& a, const h16x8& b) {
+// A tile step = three statements, each one MFMA and what is issued in its shadow.  Operands by name; an instruction
+// group that a variant does not have is an empty string, its operands are simply not named.
+#define HD_WAIT "s_waitcnt lgkmcnt(%[n])\n\t"
+#define HD_MF0 "v_mfma_f32_32x32x16_f16 %[c], %[a], %[b], 0\n\t"
+#define HD_MFA "v_mfma_f32_32x32x16_f16 %[c], %[a], %[b], %[c]\n\t"
+#define HD_RD "ds_read_b128 %[nf], %[ad] offset:%[off]\n\t"
+#define HD_SP1 "v_mul_f32 %[t0], %[x0], %[sc]\n\tv_mul_f32 %[t1], %[x1], %[sc]\n\tv_cvt_pk_f16_f32 %[H], %[t0], %[t1]\n\tv_cvt_f32_f16 %[t2], %[H]\n\t"
+#define HD_SP2 "v_cvt_f32_f16_sdwa %[t3], %[H] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t" \
+               "v_sub_f32 %[t0], %[t0], %[t2]\n\tv_sub_f32 %[t1], %[t1], %[t3]\n\tv_cvt_pk_f16_f32 %[L], %[t0], %[t1]\n\t"
+#ifndef OCN_X_HD_NOGLDS   /* timing experiment (tools/headsbench.py): no weight traffic */
+#define HD_DMA "s_add_u32 m0, %[ld], %[imm]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[vo], %[gb]\n\t"
+#else
+#define HD_DMA "s_add_u32 m0, %[ld], %[imm]\n\t"
+#endif
+
+// statement 1: (wait until at most N LDS reads are outstanding) acc (+)= wh . xl; the hi fragment of the tile three
+// steps ahead; first half of an operand split: t = x * sc, H = f16x2(t0, t1), t2 = f32(H.lo)
+template <bool CZ, int N, bool PF, int OFF, bool SP>
+__device__ __forceinline__ void hd_s1(f32x16& c, const h16x8& a, const h16x8& b, h16x8& nf, unsigned ad, float x0, float x1, float sc,
+                                      unsigned& H, float& t0, float& t1, float& t2) {
+  static_assert(OFF >= 0 && OFF < 65536 && N >= 0 && N < 16, "immediates");
+#define HD_S1(MF, CC, RD, SP1, OUTS, INS) asm volatile(HD_WAIT MF RD SP1 : [c] CC(c) OUTS : [a] "v"(a), [b] "v"(b), [n] "i"(N) INS)
+#define HD_O_RD , [nf] "=&v"(nf)      /* early clobber: the read lands while the statement still reads its inputs */
+#define HD_I_RD , [ad] "v"(ad), [off] "i"(OFF)
+#define HD_O_SP , [H] "=&v"(H), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2)
+#define HD_I_SP , [x0] "v"(x0), [x1] "v"(x1), [sc] "v"(sc)
   if constexpr (CZ) {
-    if constexpr (N >= 0) asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b), "i"(N));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=a"(c) : "v"(a), "v"(b));
+    if constexpr (PF && SP) HD_S1(HD_MF0, "=a", HD_RD, HD_SP1, HD_O_RD HD_O_SP, HD_I_RD HD_I_SP);
+    else if constexpr (PF) HD_S1(HD_MF0, "=a", HD_RD, "", HD_O_RD, HD_I_RD);
+    else if constexpr (SP) HD_S1(HD_MF0, "=a", "", HD_SP1, HD_O_SP, HD_I_SP);
+    else HD_S1(HD_MF0, "=a", "", "", , );
   } else {
-    if constexpr (N >= 0) asm volatile("s_waitcnt lgkmcnt(%3)\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b), "i"(N));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    if constexpr (PF && SP) HD_S1(HD_MFA, "+a", HD_RD, HD_SP1, HD_O_RD HD_O_SP, HD_I_RD HD_I_SP);
+    else if constexpr (PF) HD_S1(HD_MFA, "+a", HD_RD, "", HD_O_RD, HD_I_RD);
+    else if constexpr (SP) HD_S1(HD_MFA, "+a", "", HD_SP1, HD_O_SP, HD_I_SP);
+    else HD_S1(HD_MFA, "+a", "", "", , );
   }
+#undef HD_S1
 }
 
-// one weight fragment (1 KiB per wave) from the ring; `f` is in flight until the hd_mfma that waits for it
+// statement 2: acc += wl . xh; the lo fragment of the tile three steps ahead; second half of the split:
+// L = f16x2(t0 - f32(H.lo), t1 - f32(H.hi))   (the differences are exact)
+template <bool PF, int OFF, bool SP>
+__device__ __forceinline__ void hd_s2(f32x16& c, const h16x8& a, const h16x8& b, h16x8& nf, unsigned ad, unsigned H, float& t0, float& t1,
+                                      float t2, unsigned& L) {
+  static_assert(OFF >= 0 && OFF < 65536, "immediates");
+  float t3;
+#define HD_S2(RD, SP2, OUTS, INS) asm volatile(HD_MFA RD SP2 : [c] "+a"(c) OUTS : [a] "v"(a), [b] "v"(b) INS)
+#define HD_O_SP2 , [L] "=&v"(L), [t3] "=&v"(t3), [t0] "+v"(t0), [t1] "+v"(t1)
+#define HD_I_SP2 , [H] "v"(H), [t2] "v"(t2)
+  if constexpr (PF && SP) HD_S2(HD_RD, HD_SP2, HD_O_RD HD_O_SP2, HD_I_RD HD_I_SP2);
+  else if constexpr (PF) HD_S2(HD_RD, "", HD_O_RD, HD_I_RD);
+  else if constexpr (SP) HD_S2("", HD_SP2, HD_O_SP2, HD_I_SP2);
+  else HD_S2("", "", , );
+#undef HD_S2
+}
+
+// statement 3: acc += wh . xh; one LDS-DMA piece: 64 lanes x 16 bytes from gb + vo to the LDS byte address ld + IMM
+// (+ 16 lane).  M0 is written and read in ONE statement; the compiler keeps nothing in M0 in this kernel (audited).
+template <bool DMA, int IMM>
+__device__ __forceinline__ void hd_s3(f32x16& c, const h16x8& a, const h16x8& b, unsigned vo, const char* gb, unsigned ld) {
+  if constexpr (DMA) asm volatile(HD_MFA HD_DMA : [c] "+a"(c) : [a] "v"(a), [b] "v"(b), [vo] "v"(vo), [gb] "s"(gb), [ld] "s"(ld), [imm] "i"(IMM) : "memory", "scc");
+  else asm volatile(HD_MFA : [c] "+a"(c) : [a] "v"(a), [b] "v"(b));
+}
+
+// one weight fragment (1 KiB per wave) from the ring; `f` is in flight until the hd_s1 that waits for it
 template <int OFF>
 __device__ __forceinline__ void hd_dsread(h16x8& f, unsigned addr) {
   static_assert(OFF >= 0 && OFF < 65536, "ds offset");
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "i"(OFF));
 }
 
-// operand split of two activations, first half: t = x * sc, H = f16x2(t0, t1), t2 = f32(H.lo)
-__device__ __forceinline__ void hd_split1(float x0, float x1, float sc, unsigned& H, float& t0, float& t1, float& t2) {
-  asm volatile("v_mul_f32 %1, %4, %6\n\tv_mul_f32 %2, %5, %6\n\tv_cvt_pk_f16_f32 %0, %1, %2\n\tv_cvt_f32_f16 %3, %0"
-               : "=&v"(H), "=&v"(t0), "=&v"(t1), "=&v"(t2) : "v"(x0), "v"(x1), "v"(sc));
-}
-// second half: L = f16x2(t0 - f32(H.lo), t1 - f32(H.hi))   (the differences are exact)
-__device__ __forceinline__ void hd_split2(unsigned H, float t0, float t1, float t2, unsigned& L) {
-  float t3;
-  asm volatile("v_cvt_f32_f16_sdwa %1, %4 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n\t"
-               "v_sub_f32 %2, %2, %5\n\tv_sub_f32 %3, %3, %1\n\tv_cvt_pk_f16_f32 %0, %2, %3"
-               : "=&v"(L), "=&v"(t3), "+v"(t0), "+v"(t1) : "v"(H), "v"(t2));
+// operand split of two activations outside a k-step (the first k-step's operand)
+__device__ __forceinline__ void hd_split(float x0, float x1, float sc, unsigned& H, unsigned& L) {
+  float t0, t1, t2, t3;
+  asm volatile(HD_SP1 HD_SP2 : [H] "=&v"(H), [L] "=&v"(L), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+               : [x0] "v"(x0), [x1] "v"(x1), [sc] "v"(sc));
 }
 
-// one LDS-DMA piece: 64 lanes x 16 bytes from base + voff to the LDS byte address `lds` (+ 16 lane).  M0 is written
-// and read in ONE statement and handed back (§5.7: M0 is compiler-reserved); the s_nop covers SALU -> VMEM SGPR reads.
-__device__ __forceinline__ void hd_dma(unsigned voff, const char* base, unsigned lds) {
-#ifndef OCN_X_HD_NOGLDS   /* timing experiment (tools/headsbench.py): no weight traffic */
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 3\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds) : "memory");
-#endif
+// one LDS-DMA piece outside a k-step
+__device__ __forceinline__ void hd_dma(unsigned vo, const char* gb, unsigned ld) {
+  asm volatile(HD_DMA : : [vo] "v"(vo), [gb] "s"(gb), [ld] "s"(ld), [imm] "i"(0) : "memory", "scc");
 }
 
 // 16 bytes of a lane's input row; `v` is in flight until hd_xwait
@@ -217,11 +258,8 @@ struct Heads {
     h16x8 fh[4], fl[4];
     unsigned xb[2][2][4];             // [k-step parity][hi, lo][4 registers]: the B operand
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {     // operand of k-step 0
-      float t0, t1, t2;
-      hd_split1(in[p >> 1][2 * (p & 1)], in[p >> 1][2 * (p & 1) + 1], sc, xb[0][0][p], t0, t1, t2);
-      hd_split2(xb[0][0][p], t0, t1, t2, xb[0][1][p]);
-    }
+    for (int p = 0; p < 4; ++p)       // operand of k-step 0
+      hd_split(in[p >> 1][2 * (p & 1)], in[p >> 1][2 * (p & 1) + 1], sc, xb[0][0][p], xb[0][1][p]);
     hd_dsread<0>(fh[0], rg.pa[0]);
     hd_dsread<1024>(fl[0], rg.pa[0]);
     hd_dsread<2048>(fh[1], rg.pa[0]);
@@ -229,32 +267,31 @@ struct Heads {
     hd_dsread<4096>(fh[2], rg.pa[0]);
     hd_dsread<5120>(fl[2], rg.pa[0]);
     float st0[4], st1[4], st2[4];     // split state between the two halves of a tile step
+    h16x8 nof;                        // (operands a variant does not name)
+    float nox = 0.f;
+    unsigned nou = 0;
     hd_unroll<G>([&](auto gc) {
       constexpr int g = decltype(gc)::value;
       constexpr int s = g / NT, t = g % NT, c = s / 2, q = g % TPC, f = g % 4;
       constexpr int g3 = g + 3, c3 = g3 / TPC, q3 = g3 % TPC, f3 = g3 % 4;
       constexpr bool pf = g3 < G;                                      // fragments of the tile three steps ahead
       constexpr bool sp = s + 1 < KS && t < 4;                         // a quarter of the next k-step's operand
-      constexpr int sn = s + 1, si = 4 * (sn / 2) + 2 * (sn & 1) + (t >> 1), sj = 2 * (t & 1);
+      constexpr int sn = s + 1, si = sp ? 4 * (sn / 2) + 2 * (sn & 1) + (t >> 1) : 0, sj = 2 * (t & 1), tq = sp ? t : 0;
       // the chunk boundary, three tile steps early (the first read of the next chunk is this step's prefetch): the
       // pieces of the next chunk were issued a chunk ago; younger are only the pieces this chunk has issued so far
       if constexpr (q == TPC - 3 && !(LAST && c == NCH - 1)) hd_sync<(LAST && c + 2 >= NCH) ? 0 : piece_of(TPC - 3)>();
-      // LDS reads are issued in the order hi(0) lo(0) hi(1) lo(1) ...: read 2g must be back before the first MFMA
-      constexpr int issued1 = 2 * (g + 3) < 2 * G ? 2 * (g + 3) : 2 * G;
-      hd_mfma<s == 0, issued1 - (2 * g + 1)>(acc[t], fh[f], hd_frag(xb[s & 1][1]));                 // wh . xl
-      if constexpr (pf) hd_dsread<q3 * 2048>(fh[f3], rg.pa[c3 % 3]);
-      if constexpr (sp) hd_split1(in[si][sj], in[si][sj + 1], sc, xb[sn & 1][0][t], st0[t], st1[t], st2[t]);
-      constexpr int issued2 = pf ? 2 * g3 + 1 : 2 * G;
-      hd_mfma<false, issued2 - (2 * g + 2)>(acc[t], fl[f], hd_frag(xb[s & 1][0]));                  // wl . xh
-      if constexpr (pf) hd_dsread<q3 * 2048 + 1024>(fl[f3], rg.pa[c3 % 3]);
-      if constexpr (sp) hd_split2(xb[sn & 1][0][t], st0[t], st1[t], st2[t], xb[sn & 1][1][t]);
-      hd_mfma<false, -1>(acc[t], fh[f], hd_frag(xb[s & 1][0]));                                      // wh . xh
+      // LDS reads are issued in the order hi(0) lo(0) hi(1) lo(1) ...: reads 2g and 2g + 1 must be back
+      constexpr int issued = 2 * (g + 3) < 2 * G ? 2 * (g + 3) : 2 * G;
+      hd_s1<s == 0, issued - (2 * g + 2), pf, q3 * 2048, sp>(acc[t], fh[f], hd_frag(xb[s & 1][1]), pf ? fh[f3] : nof, rg.pa[c3 % 3],
+                                                             sp ? in[si][sj] : nox, sp ? in[si][sj + 1] : nox, sc,
+                                                             sp ? xb[sn & 1][0][tq] : nou, st0[tq], st1[tq], st2[tq]);        // wh . xl
+      hd_s2<pf, q3 * 2048 + 1024, sp>(acc[t], fl[f], hd_frag(xb[s & 1][0]), pf ? fl[f3] : nof, rg.pa[c3 % 3], xb[sn & 1][0][tq],
+                                      st0[tq], st1[tq], st2[tq], sp ? xb[sn & 1][1][tq] : nou);                                 // wl . xh
       // one piece of the chunk two ahead behind the tile steps that carry no operand split
-      if constexpr (has_piece(q) && !(LAST && c + 2 >= NCH)) {
-        constexpr int c2 = c + 2, j = piece_of(q);
-        const char* src = (c2 < NCH ? p_cur + (size_t)c2 * CHB : p_nxt + (size_t)(c2 - NCH) * CHB) + (size_t)j * 4096;
-        hd_dma(lane16, src, rg.ld[c2 % 3] + j * 4096);
-      }
+      constexpr bool dma = has_piece(q) && !(LAST && c + 2 >= NCH);
+      constexpr int c2 = c + 2, jp = piece_of(q);
+      const char* src = c2 < NCH ? p_cur + (size_t)c2 * CHB : p_nxt + (size_t)(c2 - NCH) * CHB;
+      hd_s3<dma, jp * 4096>(acc[t], fh[f], hd_frag(xb[s & 1][0]), lane16 + jp * 4096, src, rg.ld[c2 % 3]);                    // wh . xh
       // the next rows' tile c into the registers of this layer's input tile c (last read: step 3 of chunk c)
       if constexpr (XP && q >= 4 && q < 8) hd_xload<(32 * c + 8 * (q - 4)) * 4>(in[4 * c + (q - 4)], xnext);
     });
@@ -511,8 +548,7 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
     // ---- lin: LayerNorm, ReLU, Linear(H, 1) on the accumulator file (the VGPR set already holds the next rows) -----
     f32x4 s4 = (f32x4)(0.f);
     {
-      // ((share a + share b) + share c) + folded bias; a skipped branch's share is its constant.  The parked shares of
-      // tile t + 1 are requested before tile t is combined.
+      // ((share a + share b) + share c) + folded bias; a skipped branch's share is its constant
       typedef const __attribute__((address_space(1))) f32x4* gf4_t;          // (global, not flat: flat loads count out of order)
       gf4_t pk = (gf4_t)park;
       asm volatile("" : "+s"(pk));          // (opaque per tile: or the 64 load addresses are hoisted out of the tile loop and spilled)
@@ -521,21 +557,21 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
       asm volatile("" : "+s"(ck));
       gf4_t pa = wgA ? pk : ck;
       gf4_t pb = (wgB ? pk : ck) + (size_t)(NT * 4) * 64;
-      f32x4 na[4], nb[4];
+      f32x4 na[3][4], nb[3][4];            // the parked shares of tiles t + 1, t + 2 are requested before tile t is combined
       auto fetch = [&](int t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          na[g] = pa[(4 * t + g) * 64 + lane];
-          nb[g] = pb[(4 * t + g) * 64 + lane];
+          na[t % 3][g] = pa[(4 * t + g) * 64 + lane];
+          nb[t % 3][g] = pb[(4 * t + g) * 64 + lane];
         }
       };
       fetch(0);
+      fetch(1);
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        f32x4 ca[4], cb[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { ca[g] = na[g]; cb[g] = nb[g]; }
-        if (t + 1 < NT) fetch(t + 1);
+        if (t + 2 < NT) fetch(t + 2);
+        const f32x4 (&ca)[4] = na[t % 3];
+        const f32x4 (&cb)[4] = nb[t % 3];
         f32x16 o;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {

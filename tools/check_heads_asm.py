@@ -6,7 +6,8 @@ asm statement nor pads its hazards).  Compiles ocn_amd/csrc/heads.hip to assembl
      corruption);
   2. no VALU result is an MFMA A/B operand within the next 2 wait states;
   3. no non-MFMA instruction touches an MFMA's result within 12 wait states;
-  4. no scratch (private memory) access.
+  4. no scratch (private memory) access, no flat access (its counters retire out of order);
+  5. M0 appears only inside asm statements (the LDS-DMA statements write it and do not hand it back).
 
     python tools/check_heads_asm.py [file.s]          exit code 0 = clean
 """
@@ -66,10 +67,17 @@ def audit(path):
         vm = []                            # the same for vector-memory operations (loads, stores, LDS-DMA count together)
         recent = []                        # (wait states ago, kind, written regs) of the last instructions
         n_mfma = n_read = 0
+        in_asm = False
         for ln, line in enumerate(lines):
+            if "#ASMSTART" in line:
+                in_asm = True
+            elif "#ASMEND" in line:
+                in_asm = False
             op, ops = split_ops(line)
             if op is None:
                 continue
+            if not in_asm and re.search(r"\bm0\b", line.split(";")[0]):
+                problems.append(f"{fn}:{ln}: compiler code uses M0: {line.strip()}")
             if "scratch_" in op or op.startswith("buffer_") and "offen" in line and "lds" not in line:
                 problems.append(f"{fn}:{ln}: scratch access: {line.strip()}")
             touched = regs(" ".join(ops))
