@@ -318,9 +318,6 @@ int ocn_order_by_node(const int64_t* node, int64_t B, int64_t n_nodes, int64_t* 
   int32_t* counts = (int32_t*)workspace;
   i64* offs = (i64*)((char*)workspace + order_counts_bytes(n_nodes));
   void* scan_ws = (void*)(offs + n_nodes + 1);
-#ifdef OCN_X_ORDER_MEMSET   /* experiment of tools/graph_fault_ab.py only: the round-1 form, a memset node in a captured batch */
-  if (hipMemsetAsync(counts, 0, (size_t)n_nodes * 4, st) != hipSuccess) return OCN_EINVAL;
-#endif
   const int grid = grid_for((B + OCN_BLOCK - 1) / OCN_BLOCK, 1024);
   hipLaunchKernelGGL(order_count, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)node, (i64)B, counts);
   return ocn_order_by_node_finish(node, B, n_nodes, order, workspace, stream);

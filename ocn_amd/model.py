@@ -24,8 +24,6 @@ from . import ops
 from .sparse import SparseTensor
 from .utils import fuse
 
-_X_CAPTURE_QUERY = bool(os.environ.get("OCN_X_CAPTURE_QUERY"))   # tools/graph_fault_ab.py: the round-1 behaviour
-
 
 # ------------------------------------------------------------------------------------------
 # edge dropout (model.py:198-229) — identity in eval; train-time regulariser
@@ -583,7 +581,7 @@ class _CNPredictorBase(nn.Module):
         pr = getattr(self, "_skip_state", None)
         if pr is None:
             return True
-        if torch.cuda.is_current_stream_capturing() and not _X_CAPTURE_QUERY:   # no event query while capturing:
+        if torch.cuda.is_current_stream_capturing():                           # no event query while capturing:
             return pr["off"] == 0                                                # replay what was last decided
         if pr["pending"] is not None and pr["pending"].query():
             r = pr["host"]

@@ -6,6 +6,7 @@ CUDA(HIP) tensors and raises if the library is missing — there is no CPU path.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -572,6 +573,9 @@ def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int):
 
 
 dense_adj2_max_nodes = 32768      # block route: A as a dense int8 matrix (n^2 bytes, twice) up to this many nodes
+# utils.sparse_tensor_multiply (the drivers' --adj2byblock call, NeighborOverlap_large.py:116): False = the intended A²,
+# True = the reference as written (utils.py:318-321, SURVEY Q7: block-local indices, all blocks folded onto one corner)
+adj2_fold_quirk = os.environ.get("OCN_ADJ2_FOLD_QUIRK", "0") == "1"
 
 
 @_on_device

@@ -44,6 +44,18 @@ class _Storage:
 
 
 class SparseTensor:
+    def __new__(cls, row=None, rowptr=None, col=None, value=None, sparse_sizes=None, *a, **k):
+        # `torch_sparse.SparseTensor(row=row1, col=col1, value=value1, sparse_sizes=(B, N))` at the end of the pygho drivers'
+        # get_cn1_cn2 (NeighborOverlap_large_ppa.py:170-171) on the deferred vectors of shims/pygho: the handle itself
+        cn = getattr(row, "_ocn_lazy_cn", None)
+        if cn is not None:
+            if getattr(col, "_ocn_lazy_cn", None) is not cn or (value is not None and getattr(value, "_ocn_lazy_cn", None) is not cn):
+                raise NotImplementedError("row / col / value of different deferred common-neighbour matrices")
+            if sparse_sizes is not None and tuple(int(v) for v in sparse_sizes) != tuple(cn.shape):
+                raise ValueError(f"sparse_sizes {tuple(sparse_sizes)} != {tuple(cn.shape)} of the deferred matrix")
+            return cn.batch()
+        return super().__new__(cls)
+
     def __init__(self, row: Optional[Tensor] = None, rowptr: Optional[Tensor] = None,
                  col: Optional[Tensor] = None, value: Optional[Tensor] = None,
                  sparse_sizes: Optional[Tuple[int, int]] = None, is_sorted: bool = False,

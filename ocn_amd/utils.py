@@ -359,5 +359,7 @@ def block_matrix_multiply(spadj: SparseTensor, block_size: int, fold_quirk: bool
 
 
 def sparse_tensor_multiply(spadj: SparseTensor, block_size: int = 1024) -> SparseTensor:
-    """utils.py:326-329."""
-    return block_matrix_multiply(spadj, block_size)
+    """utils.py:326-329.  Which reading of utils.py:318-321 the unchanged ddi command gets is a process-wide
+    switch: ``ops.adj2_fold_quirk`` (environment ``OCN_ADJ2_FOLD_QUIRK=1``) selects the reference as written — every
+    block folded onto the top-left corner; the default is the intended offset-correct A²."""
+    return block_matrix_multiply(spadj, block_size, fold_quirk=bool(ops.adj2_fold_quirk))

@@ -1,0 +1,3 @@
+from _shimguard import shadowing as _shadowing
+
+_shadowing("ogb")

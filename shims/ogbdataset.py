@@ -1,10 +1,18 @@
 """`from ogbdataset import loaddataset` (NeighborOverlap_large.py:16): same return contract as the reference's
-ogbdataset.loaddataset(name, use_valedges_as_input, load=None) (/ogbdataset.py:29-71) on a seeded synthetic graph."""
+ogbdataset.loaddataset(name, use_valedges_as_input, load=None) (/ogbdataset.py:29-71) on a seeded synthetic graph —
+served only after an explicit opt-in (OCN_SYNTH=1) and announced on stderr, so that the Hits@K / MRR a driver then prints
+cannot be mistaken for results on the real dataset."""
 import os
+import sys
 
 import torch
 
+from _shimguard import require_synth
 from ocn_amd.synth import loaddataset_like
+
+SEED = 0
+# shapes ocn_amd.synth knows; Citeseer / Pubmed have no shape of their own there
+SHAPES = {"Cora": "cora", "collab": "collab", "ppa": "ppa", "citation2": "citation2", "ddi": "ddi"}
 
 
 class Data:
@@ -22,7 +30,12 @@ class Data:
 
 
 def loaddataset(name: str, use_valedges_as_input: bool, load=None):
-    shape = {"Cora": "cora", "Citeseer": "cora", "Pubmed": "cora"}.get(name, name)
+    require_synth(f"ogbdataset.loaddataset({name!r})")
+    if name not in SHAPES:
+        raise ValueError(f"ogbdataset.loaddataset({name!r}): no synthetic shape for this dataset (known: {sorted(SHAPES)}); "
+                         "a graph of another dataset's shape under this name would only mislead")
     scale = float(os.environ.get("OCN_SYNTH_SCALE", "1.0"))
-    data, split_edge = loaddataset_like(shape, use_valedges_as_input, seed=0, scale=scale)
+    print(f"[ocn shims] SYNTHETIC DATA: '{name}' is a seeded Chung-Lu graph of the {SHAPES[name]} shape (seed {SEED}, scale {scale}); "
+          "metrics printed on it are not results on the real dataset", file=sys.stderr, flush=True)
+    data, split_edge = loaddataset_like(SHAPES[name], use_valedges_as_input, seed=SEED, scale=scale)
     return Data(data), split_edge

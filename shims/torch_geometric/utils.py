@@ -9,7 +9,7 @@ def negative_sampling(edge_index, num_nodes=None, num_neg_samples=None, **kwargs
     key = torch.unique(edge_index[0].long() * n + edge_index[1].long())
     out = []
     need = m
-    for _ in range(8):
+    for _ in range(64):                                    # rejection sampling, topped up until the count is met
         if need <= 0:
             break
         cand = torch.randint(0, n * n, (int(need * 1.2) + 16,), device=edge_index.device)
@@ -18,6 +18,8 @@ def negative_sampling(edge_index, num_nodes=None, num_neg_samples=None, **kwargs
         cand = cand[ok][:need]
         out.append(cand)
         need -= cand.numel()
+    if need > 0:
+        raise RuntimeError(f"negative_sampling: the graph is too dense to draw {m} non-edges ({m - need} found)")
     c = torch.cat(out) if out else torch.zeros(0, dtype=torch.long, device=edge_index.device)
     return torch.stack([torch.div(c, n, rounding_mode="floor"), c % n])
 

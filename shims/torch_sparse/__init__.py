@@ -1,5 +1,8 @@
 """`from torch_sparse import SparseTensor` (NeighborOverlap_large.py:6) -> ocn_amd.sparse.SparseTensor: the
 torch_sparse surface the drivers and utils.py touch, over int64 rowptr + int32 col resident in HBM."""
+from _shimguard import shadowing as _shadowing
+
+_shadowing("torch_sparse")
 from ocn_amd.sparse import SparseTensor  # noqa: F401
 
 

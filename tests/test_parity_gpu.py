@@ -569,6 +569,51 @@ def test_walk_route_counts_values_and_pools(case):
         assert torch.equal(g2.cpu(), r2), (g2.cpu() - r2).abs().max()     # valued cn2, innerprod != 0 included
 
 
+def test_pygho_shim_scores_equal_the_direct_handles(case):
+    """The drivers' own get_cn1_cn2 (restated in tests/test_shims.py), executed against shims/pygho on the GPU: same
+    counts, same explicit matrices and bit-identical scores as ocn_amd.utils.get_cn1_cn2 — for both predictors of the
+    pygho drivers — and a deferred vector touched as a tensor materialises the explicit matrix."""
+    from tests.test_shims import pygho_namespace
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import get_cn1_cn2
+    ns = pygho_namespace()
+    adj = ns["wrap"](case.adj)
+    e = case.e.to(DEV)
+    s1, s2 = ns["get_cn1_cn2"](adj, e)
+    d1, d2 = get_cn1_cn2(case.adj, e)
+    assert torch.equal(s1.counts(), d1.counts()) and torch.equal(s2.counts(), d2.counts())
+    oc1, oc2 = O.get_cn1_cn2(case.oadj, case.e)
+    assert spm_equal(s1.materialize(), oc1) and spm_equal(s2.materialize(), oc2)
+    torch.manual_seed(4)
+    x = torch.randn(case.n, 64, device=DEV)
+    for name in ("cn5", "cn7"):
+        pred = predictor_dict[name](64, 64, 1, 3, 0.0, 0.0, True).to(DEV).eval()
+        args = SimpleNamespace(sum=0.0)
+        with torch.no_grad():
+            via_shim = pred(x, adj, ns["get_cn1_cn2"](adj, e)[0], ns["get_cn1_cn2"](adj, e)[1], e, args)   # …_ppa.py:201: two calls
+            direct = pred(x, case.adj, d1, d2, e, args)
+        assert torch.equal(via_shim, direct)
+    # the deferred vectors as tensors
+    from pygho.backend.Spspmm import spsphadamard, spspmm
+    Ei, Ej = adj.index_select([0], e[0].unsqueeze(0)), adj.index_select([0], e[1].unsqueeze(0))
+    coo = spsphadamard(Ei, spspmm(Ej, 1, adj, 0)).to_torch_sparse_coo()
+    row, col = coo.indices()
+    assert row.cpu().tolist() == oc2.row.tolist() and col.cpu().tolist() == oc2.col.tolist()
+    assert coo.values().cpu().tolist() == oc2.val.tolist()
+
+
+def test_fold_quirk_switch_on_the_ddi_call(hiplib, monkeypatch):
+    """ops.adj2_fold_quirk routes utils.sparse_tensor_multiply — the unchanged ddi command's call — to either reading of
+    utils.py:318-321; both equal the oracle's."""
+    from ocn_amd import ops
+    from ocn_amd.utils import sparse_tensor_multiply
+    oadj = make_graph(700, 60, 300, 77)
+    adj = to_product(oadj, DEV)
+    assert spm_equal(sparse_tensor_multiply(adj, 256), O.adj2_by_block(oadj, 256))
+    monkeypatch.setattr(ops, "adj2_fold_quirk", True)
+    assert spm_equal(sparse_tensor_multiply(adj, 256), O.adj2_by_block(oadj, 256, fold_quirk=True))
+
+
 def _walk_raw(adj, e, nds):
     from ocn_amd import ops
     order, off, flags, wc, hist, c1, c2, status, _ = ops.cn_flags(
