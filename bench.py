@@ -364,7 +364,7 @@ def main():
     pred.set_edge_sharding(None, enabled=world > 1 or args.rehearse_collectives)
 
     pending = [None]                               # the previous batch's score all-gather (N > 1), still in flight
-    kept = None                                    # per-rank scores of the timed loop's batches (N > 1), gathered once at its end
+    pattern = ["single rank: no collective"]          # the communication pattern of the timed loop, reported in the JSON line
     # N > 1: two batches in flight — the intersection pass of batch t + 1 is enqueued before batch t waits for its
     # histogram all-reduce (predictor.begin / .finish), so the collective runs beside compute instead of stalling the
     # stream.  The timed loop still begins and finishes exactly K batches between its barriers.
@@ -386,10 +386,7 @@ def main():
             else:
                 c1, c2 = cn_handles(wl, mine)
                 loc = pred(h, adj, c1, c2, mine, wl["args"])
-            if pipelined and kept is not None:     # timed loop, N > 1: a scoring loop consumes its scores at the end —
-                kept.append(loc)                   # every rank keeps its slices and ONE all-gather closes the loop
-                return loc
-            # otherwise gather per batch; the all-gather of batch t runs beside batch t + 1 (its own stream)
+            # warm-up / validation steps: gather per batch; the all-gather of batch t runs beside batch t + 1 (its own stream)
             if pending[0] is not None:
                 pending[0].wait()
             out, pending[0] = gather_scores(loc, B_total, async_op=True)
@@ -441,33 +438,44 @@ def main():
         t0 = time.perf_counter()
         t_wait = 0.0
         out = None
-        nonlocal kept
-        kept = [] if pipelined else None
-        for it in range(steps):
+        t_waits = [0.0]
+
+        def before_step(it):
             tw = time.perf_counter()
             ring[it % run_ahead].synchronize()
-            t_wait += time.perf_counter() - tw
+            t_waits[0] += time.perf_counter() - tw
             if timer:                                  # stage events on every `timer_every`-th step only: on a busy
                 timer.active = it % args.timer_every == 0   # host each hipEventRecord costs tens of microseconds
                 timer.mark("begin")
-            out = step(it, last=(it == steps - 1))
+
+        def after_step(it):
             if timer:
                 timer.mark("mlp_glue")
             ring[it % run_ahead].record()
+
+        if pipelined:
+            # N > 1 (or the one-rank rehearsal): the library's own sharded scoring loop — two batches in flight, every
+            # rank keeps its slices, ONE all-gather closes the loop inside the timed region
+            from ocn_amd.pipeline import pipelined_shard_loop
+            with torch.no_grad():
+                scores, pattern[0] = pipelined_shard_loop(begin, lambda tok: pred.finish(h, tok, wl["args"]), steps, B_total,
+                                                          gather_at_end=True, before_step=before_step, after_step=after_step)
+            out = scores[-1]
+        else:
+            for it in range(steps):
+                before_step(it)
+                out = step(it, last=(it == steps - 1))
+                after_step(it)
+        t_wait = t_waits[0]
         t_launch = time.perf_counter() - t0 - t_wait    # host time spent enqueueing (flow-control waits excluded)
         if pending[0] is not None:
             pending[0].wait()
             pending[0] = None
-        if kept:                                        # the loop's one score all-gather, inside the timed region
-            allsc = gather_scores(torch.cat(kept, 0), len(kept) * B_total)
-            per = kept[0].shape[0]
-            out = allsc.view(world, len(kept), per, -1)[:, -1].reshape(world * per, -1)     # the last batch, in batch order
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        kept = None
         ops.stage_timer = None
         if world > 1:
             tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -597,6 +605,7 @@ def main():
             "algorithmic_bytes_per_step": ab["flags_compulsory"] + ab["gather_compulsory"],
             "survey_formula_bytes_per_step": ab["flags_formula"] + ab["gather_formula"],
             "host_enqueue_ms_per_step": t_launch / args.steps * 1e3,
+            "communication_pattern": pattern[0],
             "parity_on_cpu_sample_max_abs_err": err,
             "parity_on_cpu_sample_max_abs_ref": ref_scale,         # the scores' scale: raw walk-count pools (citation2) reach 1e4
             "parity_on_cpu_sample_rel_err": None if not ref_scale else err / ref_scale,
@@ -610,4 +619,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:                                       # the timed loops switch the per-batch id check off: never leave it off
+        from ocn_amd import ops as _ops
+        _ops.validate_indices = True

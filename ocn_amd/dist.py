@@ -155,16 +155,75 @@ def gather_scores(local: Tensor, total: int, group=None, async_op: bool = False)
 def sharded_predict(predictor, h: Tensor, adj, adj2, edges: Tensor, args=None, group=None) -> Tensor:
     """Score the global candidate batch ``edges`` [2, B] with the batch cut over the ranks of
     ``group``; every rank returns the full [B, 1] score vector, equal to the single-device result
-    on the same batch."""
+    on the same batch.  In eval under no_grad it takes the predictor's two-phase path (``begin`` / ``finish``): the
+    histogram sum runs on the whole interleaved buffer — no copy-out / copy-back of the packed word — as in the
+    pipelined loop (``pipeline.pipelined_shard_loop``)."""
     from .utils import adjoverlap
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     check_global_batch(edges.shape[1])
     s, e = shard_bounds(edges.shape[1], world)[rank]
     mine = edges[:, s:e].contiguous()
-    predictor.set_edge_sharding(group if world > 1 else None, enabled=world > 1)
+    predictor.set_edge_sharding(group if world > 1 else None, enabled=world > 1 or force_collectives)
     try:
-        local = predictor(h, adj, adjoverlap(adj, adj, mine), adjoverlap(adj, adj2, mine), mine, args)
+        c1, c2 = adjoverlap(adj, adj, mine), adjoverlap(adj, adj2, mine)
+        if not predictor.training and not torch.is_grad_enabled():
+            local = predictor.finish(h, predictor.begin(h, adj, c1, c2, mine), args)
+        else:
+            local = predictor(h, adj, c1, c2, mine, args)
     finally:
         predictor.set_edge_sharding(None, enabled=False)
     return gather_scores(local, edges.shape[1], group)
+
+
+# ---------------------------------------------------------------------------------------------
+# dry run: what an N-rank run holds per GPU and moves per batch (no GPU, no process group needed)
+# ---------------------------------------------------------------------------------------------
+XGMI_LINK_GBPS = 153.0           # per link and direction; 7 links per GPU, full mesh (MI355X_MICROARCH.md / task notes)
+SHAPES = {
+    # name: nodes, stored entries of A, entries of A² (None: walk route, no A²), H, candidates per rank, valued histogram
+    "collab": dict(n=235_868, nnz=2_360_000, nnz2=127_996_321, H=256, batch=65_536, walk=False, bitrows=True, mean_deg=38),
+    "citation2": dict(n=2_927_963, nnz=60_000_000, nnz2=None, H=32, batch=2_048, walk=True, bitrows=False, mean_deg=90),
+}
+
+
+def shard_plan(shape: str = "collab", worlds=(1, 2, 4, 8)) -> List[dict]:
+    """Per world size: bytes resident per GPU (everything but the candidate slice is replicated), bytes per collective
+    and the time they take on xGMI if RCCL reaches the link rate — a floor, not a measurement (no N > 1 run exists yet).
+    All-reduce of S bytes moves 2 (w-1)/w S per rank; spread over the min(w-1, 7) links of the mesh (direct
+    reduce-scatter + all-gather) or over ONE link (ring).  Weak scaling: ``batch`` candidates per rank."""
+    c = SHAPES[shape]
+    n, H, B = c["n"], c["H"], c["batch"]
+    csr = (n + 1) * 8 + c["nnz"] * 4
+    a2 = 0 if c["nnz2"] is None else (n + 1) * 8 + c["nnz2"] * 4
+    bits = n * ((n + 31) // 32) * 4 if c["bitrows"] else 0
+    hbytes = n * H * 4
+    hist = n * 16                                           # interleaved {packed counts, walk-count sums}
+    scratch = 2 * (B * c["mean_deg"] * (5 if c["walk"] else 1) + B * 32 + hist + 3 * B * H * 4) + (256 * 4 * 2 * H * 32 * 4 if H >= 128 else 0)
+    rows = []
+    for w in worlds:
+        ar = 0.0 if w == 1 else 2.0 * (w - 1) / w * hist
+        ag = 0.0 if w == 1 else (w - 1) * B * 4             # every rank receives the other ranks' slices
+        links = max(min(w - 1, 7), 1)
+        rows.append(dict(shape=shape, world=w, global_batch=w * B,
+                         resident_GB=(csr + a2 + bits + hbytes + scratch) / 1e9,
+                         graph_MB=csr / 1e6, adj2_MB=a2 / 1e6, bitrows_GB=bits / 1e9, h_MB=hbytes / 1e6, scratch_MB=scratch / 1e6,
+                         hist_allreduce_MB_per_rank=ar / 1e6, score_allgather_KB_per_rank=ag / 1e3,
+                         allreduce_us_mesh=ar / (links * XGMI_LINK_GBPS * 1e3), allreduce_us_ring=ar / (XGMI_LINK_GBPS * 1e3),
+                         allgather_us_mesh=ag / (links * XGMI_LINK_GBPS * 1e3)))
+    return rows
+
+
+def shard_plan_markdown(shapes=("collab", "citation2"), worlds=(1, 2, 4, 8)) -> str:
+    out = ["| shape | ranks | global batch | resident / GPU | of which A² + bit rows | h | histogram all-reduce / rank | floor, mesh / ring | "
+           "score all-gather / rank | floor |", "|---|---|---|---|---|---|---|---|---|---|"]
+    for sh in shapes:
+        for r in shard_plan(sh, worlds):
+            out.append(f"| {sh} | {r['world']} | {r['global_batch']} | {r['resident_GB']:.2f} GB | {r['adj2_MB'] / 1e3 + r['bitrows_GB']:.2f} GB | "
+                       f"{r['h_MB']:.0f} MB | {r['hist_allreduce_MB_per_rank']:.2f} MB | {r['allreduce_us_mesh']:.1f} / {r['allreduce_us_ring']:.1f} µs | "
+                       f"{r['score_allgather_KB_per_rank']:.0f} KB | {r['allgather_us_mesh']:.2f} µs |")
+    return "\n".join(out)
+
+
+if __name__ == "__main__":
+    print(shard_plan_markdown())

@@ -135,6 +135,8 @@ def check_edges(src: Tensor, dst: Tensor, n_src: int, n_dst: int) -> None:
     kernel would fault instead, so the ids are checked here (costs one host sync)."""
     if not validate_indices or src.numel() == 0:
         return
+    if (int(n_src), int(n_dst)) in getattr(_checked, "scopes", ()):      # inside ``prevalidated`` for an adjacency of this size
+        return
     _req(src, torch.int64, "src", 1); _req(dst, torch.int64, "dst", 1)
     bad = torch.zeros(1, dtype=torch.int32, device=src.device)
     check(_lib.lib().ocn_check_edges(ptr(src), ptr(dst), src.numel(), int(n_src), int(n_dst), ptr(bad), stream_ptr()),
@@ -143,24 +145,30 @@ def check_edges(src: Tensor, dst: Tensor, n_src: int, n_dst: int) -> None:
         raise IndexError("candidate edge endpoint out of range for the adjacency")
 
 
+import threading  # noqa: E402
+_checked = threading.local()      # .scopes: (n_src, n_dst) of the splits validated by the ``prevalidated`` scopes of THIS thread
+
+
 class prevalidated:
     """``with ops.prevalidated(src_all, dst_all, n_src, n_dst):`` — bounds-check a whole split of candidate
     edges once (one host sync), then run the batches inside without the per-batch check.  This is what
     ``pipeline.score_edges`` / ``score_mrr_split`` do: the check is hoisted out of the batch loop, the
-    exception for a bad id is the same IndexError, raised before the first batch."""
+    exception for a bad id is the same IndexError, raised before the first batch.  The waiver is scoped: it
+    holds for the calling thread only and only for adjacencies of the validated size — another thread, or a call on a
+    graph of another size inside the scope, is checked as usual (``validate_indices`` itself is not touched)."""
 
     def __init__(self, src: Tensor, dst: Tensor, n_src: int, n_dst: int):
         check_edges(src.contiguous(), dst.contiguous(), n_src, n_dst)
+        self._key = (int(n_src), int(n_dst))
 
     def __enter__(self):
-        global validate_indices
-        self._keep = validate_indices
-        validate_indices = False
+        if not hasattr(_checked, "scopes"):
+            _checked.scopes = []
+        _checked.scopes.append(self._key)
         return self
 
     def __exit__(self, *exc):
-        global validate_indices
-        validate_indices = self._keep
+        _checked.scopes.remove(self._key)
         return False
 
 

@@ -78,6 +78,51 @@ def score_mrr_split(predictor, h: Tensor, adj, source: Tensor, target: Tensor, t
     return evaluator.eval({"y_pred_pos": pos_pred, "y_pred_neg": neg_pred})["mrr_list"].mean().item()
 
 
+def pipelined_shard_loop(begin, finish, n_steps: int, batch_total: int, group=None, gather_at_end: bool = True,
+                         before_step=None, after_step=None):
+    """The edge-sharded scoring loop (bench.py's timed region at N > 1; one rank's view).  ``begin(it)`` = the predictor's
+    phase A of batch ``it`` (intersection pass + START of the histogram all-reduce) and returns a token, ``finish(token)``
+    = phase B (wait, weights, pooling, heads) and returns this rank's scores ``[b, C]``.  Two batches are in flight:
+    ``begin(it + 1)`` is enqueued before ``finish(it)``, so the all-reduce of batch ``it`` runs beside the intersection work
+    of batch ``it + 1``.  Scores: ``gather_at_end`` keeps every rank's slices and closes the loop with ONE all-gather (what a
+    scoring loop that consumes its scores afterwards wants; needs equal slices), else each batch is gathered asynchronously
+    and waited for one step later.  Returns (scores of all steps ``[n_steps, batch_total, C]`` in batch order, pattern
+    string).  ``before_step(it)`` / ``after_step(it)``: the caller's flow control and timers."""
+    from .dist import gather_scores
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if gather_at_end and batch_total % world != 0:
+        gather_at_end = False                                  # ragged slices: per-batch gather pads and trims
+    kept, outs, ahead, pending = [], [], None, None
+    for it in range(n_steps):
+        if before_step is not None:
+            before_step(it)
+        tok = ahead if ahead is not None else begin(it)
+        ahead = begin(it + 1) if it + 1 < n_steps else None
+        loc = finish(tok)
+        if gather_at_end:
+            kept.append(loc)
+        else:
+            if pending is not None:
+                pending[1].wait() if pending[1] is not None else None
+                outs.append(pending[0])
+            pending = gather_scores(loc, batch_total, group, async_op=True)
+        if after_step is not None:
+            after_step(it)
+    if pending is not None:
+        pending[1].wait() if pending[1] is not None else None
+        outs.append(pending[0])
+    if gather_at_end:
+        if not kept:
+            return None, "one all-gather at the end"
+        per = kept[0].shape[0]
+        allsc = gather_scores(torch.cat(kept, 0), len(kept) * batch_total, group)       # rank-major: [world][n_steps][per]
+        w = allsc.shape[0] // (len(kept) * per)
+        scores = allsc.view(w, len(kept), per, -1).permute(1, 0, 2, 3).reshape(len(kept), w * per, -1)
+        return scores, "two batches in flight (begin/finish), local scores kept, ONE all-gather closes the loop"
+    return (torch.stack(outs, 0) if outs else None), "two batches in flight (begin/finish), one async all-gather per batch"
+
+
 class GraphedScorer:
     """One candidate batch of a FIXED size as a captured HIP graph: ~40 kernel launches per batch become one
     graph launch.  For the small-batch configurations (Cora / Citeseer / Pubmed drivers: 1152-edge batches on

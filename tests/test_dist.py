@@ -142,3 +142,78 @@ def test_ring_colsum_continues_the_chain_through_the_ranks():
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res), res
+
+
+def _loop_worker(rank, world, port, B, at_end, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ocn_amd.dist import allreduce_hist_finish, allreduce_hist_start
+        from ocn_amd.pipeline import pipelined_shard_loop
+        n_cols, steps = 50, 5
+        s, e = shard_bounds(B, world)[rank]
+        order = []
+
+        def begin(it):                         # phase A of batch `it`: this rank's column counts, START of their sum
+            order.append(("begin", it))
+            ids = torch.arange(s, e) + it * B
+            hist = torch.zeros(n_cols, 2, dtype=torch.int64)
+            hist[:, 0] = torch.bincount(ids % n_cols, minlength=n_cols)
+            return it, ids, hist, allreduce_hist_start(hist, valued=True)
+
+        def finish(tok):                       # phase B: wait for the sum, score = f(global count of the edge's column, edge id)
+            it, ids, hist, handle = tok
+            order.append(("finish", it))
+            allreduce_hist_finish(handle)
+            return (hist[ids % n_cols, 0].float() * 1000 + ids.float()).reshape(-1, 1)
+
+        hooks = []
+        scores, pattern = pipelined_shard_loop(begin, finish, steps, B, gather_at_end=at_end,
+                                               before_step=lambda it: hooks.append(("b", it)), after_step=lambda it: hooks.append(("a", it)))
+        want = []
+        for it in range(steps):
+            ids = torch.arange(B) + it * B
+            cnt = torch.bincount(ids % n_cols, minlength=n_cols)
+            want.append((cnt[ids % n_cols].float() * 1000 + ids.float()).reshape(-1, 1))
+        ok = scores is not None and tuple(scores.shape) == (steps, B, 1) and torch.equal(scores, torch.stack(want))
+        # two batches in flight: begin(t + 1) before finish(t), every batch begun and finished exactly once
+        exp = [("begin", 0)]
+        for it in range(steps):
+            if it + 1 < steps:
+                exp.append(("begin", it + 1))
+            exp.append(("finish", it))
+        ok_order = order == exp and hooks == [(k, it) for it in range(steps) for k in ("b", "a")]
+        out.put((rank, ok, ok_order, pattern))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,at_end", [(64, True), (64, False), (77, True)])
+def test_two_rank_pipelined_shard_loop(B, at_end):
+    """`pipeline.pipelined_shard_loop` — the function bench.py's timed region runs at N > 1 — with two gloo ranks on CPU
+    stubs of the predictor's begin / finish: scores of every step in batch order (one all-gather at the end, an async
+    gather per batch, and the ragged case falling back to per-batch gathers), begin(t + 1) enqueued before finish(t)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_loop_worker, args=(r, 2, port, B, at_end, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, ok_order, pattern in res:
+        assert ok, f"rank {rank}: scores differ from the single-process batch"
+        assert ok_order, f"rank {rank}: phase order"
+        assert ("ONE all-gather" in pattern) == (at_end and B % 2 == 0)
+
+
+def test_shard_plan_dry_run():
+    from ocn_amd.dist import shard_plan, shard_plan_markdown
+    rows = shard_plan("collab", (1, 2, 8))
+    assert rows[0]["hist_allreduce_MB_per_rank"] == 0 and rows[1]["hist_allreduce_MB_per_rank"] == pytest.approx(235868 * 16 / 1e6)
+    assert rows[2]["allreduce_us_mesh"] < rows[2]["allreduce_us_ring"] and 7.0 < rows[0]["resident_GB"] < 10.0
+    assert shard_plan_markdown().count("\n") == 1 + 2 * 4
