@@ -5,6 +5,10 @@
 // transposed into per-column entry lists — count (the histogram's n_union field, or an atomic count when a
 // second flag array joins) -> scan -> fill -> sort by flag position (positions ascend with the batch row) — and
 // one lane chain adds each column's values in that order, every product / difference rounded separately.
+// Only columns whose values are not integers need any of that: a column with fewer than two cn1 entries has t = nip *
+// inv1 = 0 (model.py:2263-2266), all its v are the cn2 values themselves (1.0, or the walk count), and their fp32 sum is
+// exact in any order below 2^24 — it is written from the histogram's counts, and its entries are neither counted,
+// filled, sorted nor chained (cn5; cn6's second stage has non-integer values in every column of the union).
 #include "common.h"
 
 #define CS_WAVE_MAX 64          /* columns with at most this many entries: one wave each */
@@ -16,10 +20,23 @@
 // ---------------------------------------------------------------------------------------------
 // entry lists
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(OCN_BLOCK) void colsum_nu_kernel(const u64* __restrict__ hist, i64 N,
+// does the order of a column's entries matter?  (t != 0: non-integer values; or an integer sum that leaves fp32's exact range)
+__device__ __forceinline__ bool cs_ordered(u64 pk, u64 walks, float nip, bool valued) {
+  const int n1 = hf_n1(pk);
+  const float t = __fmul_rn(nip, n1 >= 2 ? 1.0f / (float)n1 : 0.0f);
+  return t != 0.0f || (valued ? walks : (u64)hf_n2(pk)) >= (1ull << 24);
+}
+
+// ALL: every column of the union is ordered (cn6)
+template <bool ALL>
+__global__ __launch_bounds__(OCN_BLOCK) void colsum_nu_kernel(const u64* __restrict__ hist, i64 N, const float* __restrict__ innerprod,
+                                                              const int32_t* __restrict__ scalars, int valued,
                                                               int32_t* __restrict__ counts) {
-  for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (i64)gridDim.x * blockDim.x)
-    counts[c] = hf_nu(hist[2 * c]);
+  const float nip = cn5_nip(scalars[0], innerprod[0]);
+  for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (i64)gridDim.x * blockDim.x) {
+    const u64 pk = hist[2 * c];
+    counts[c] = (ALL || cs_ordered(pk, hist[2 * c + 1], nip, valued)) ? hf_nu(pk) : 0;
+  }
 }
 
 __global__ __launch_bounds__(OCN_BLOCK) void colsum_zero_kernel(int32_t* __restrict__ p, i64 n) {
@@ -28,12 +45,16 @@ __global__ __launch_bounds__(OCN_BLOCK) void colsum_zero_kernel(int32_t* __restr
 
 // One wave per batch row.  FILL = false: counts[k] += 1 per union entry; FILL = true: the entry's flag position
 // goes to the next free slot of its column (cursor zero on entry).
+// (FILL: a column without a list — col_off[k] == col_off[k + 1] — is an unordered one; counting: `hist` != NULL selects
+// the ordered columns by the same predicate as colsum_nu_kernel, NULL counts every column)
 template <bool FILL>
 __global__ __launch_bounds__(OCN_BLOCK) void colsum_entries_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA, const i64* __restrict__ src, i64 B,
     const i64* __restrict__ off, const uint8_t* __restrict__ flagsA, const uint8_t* __restrict__ flagsB, i64 cap,
-    const i64* __restrict__ col_off, int32_t* __restrict__ cursor, uint32_t* __restrict__ entries) {
+    const i64* __restrict__ col_off, int32_t* __restrict__ cursor, uint32_t* __restrict__ entries,
+    const u64* __restrict__ hist, const float* __restrict__ innerprod, const int32_t* __restrict__ scalars, int valued) {
   const int lane = threadIdx.x & 63;
+  const float nip = hist ? cn5_nip(scalars[0], innerprod[0]) : 0.0f;
   for (i64 e = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6); e < B; e += (i64)gridDim.x * OCN_WPB) {
     const i64 i = src[e];
     const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0, base = off[e];
@@ -43,8 +64,14 @@ __global__ __launch_bounds__(OCN_BLOCK) void colsum_entries_kernel(
       if (flagsB) f |= (unsigned)(flagsB[base + p] & OCN_F_CN1) << 2;
       if (!f) continue;
       const int32_t k = colA[a0 + p];
-      const int slot = atomicAdd(cursor + k, 1);
-      if (FILL) entries[col_off[k] + slot] = (uint32_t)(base + p);
+      if (FILL) {
+        const i64 c0 = col_off[k];
+        if (col_off[k + 1] == c0) continue;
+        entries[c0 + atomicAdd(cursor + k, 1)] = (uint32_t)(base + p);
+      } else {
+        if (hist && !cs_ordered(hist[2 * (i64)k], hist[2 * (i64)k + 1], nip, valued)) continue;
+        atomicAdd(cursor + k, 1);
+      }
     }
   }
 }
@@ -95,8 +122,14 @@ __global__ __launch_bounds__(OCN_BLOCK) void colsum_short_kernel(
   for (i64 c = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6); c < N; c += (i64)gridDim.x * OCN_WPB) {
     const i64 b = col_off[c];
     const int n = (int)(col_off[c + 1] - b);
-    if (n == 0) {                                        // no entry here: an earlier shard's partial sum passes through
-      if (s2_init && lane == 0) s2[c] = s2_init[c];
+    if (n == 0) {
+      // no list: an unordered column — its sum is the integer count itself (every rank holds the global histogram) —
+      // or, on an edge shard, an ordered column without an entry here: the earlier shards' partial sum passes through
+      if (lane == 0) {
+        const u64 pk = hist[2 * c], walks = hist[2 * c + 1];
+        if (pk != 0 && !s3 && !cs_ordered(pk, walks, cx.nip, cx.wc != nullptr)) s2[c] = cx.wc ? (float)walks : (float)hf_n2(pk);
+        else if (s2_init) s2[c] = s2_init[c];
+      }
       continue;
     }
     if (n > CS_WAVE_MAX) {
@@ -253,14 +286,17 @@ int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64
   int rc = ocn_cn5_column_stats(hist, N, scalars, stream);           // nip needs the batch's scale (idempotent)
   if (rc) return rc;
   hipLaunchKernelGGL(colsum_zero_kernel, dim3(1), dim3(OCN_BLOCK), 0, st, tickets, (i64)(4 + sw / 4));   // + the scan state
+  const int valued = wc != nullptr;
   if (flagsB || s2_init) {        // cn6: the union is wider than histA's n_union; a shard: hist holds the GLOBAL counts
     hipLaunchKernelGGL(colsum_zero_kernel, dim3(gridN), dim3(OCN_BLOCK), 0, st, counts, (i64)N);
     if (B > 0)
       hipLaunchKernelGGL((colsum_entries_kernel<false>), dim3(gridB), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA, colA,
                          (const i64*)src, (i64)B, (const i64*)off, flagsA, flagsB, (i64)flags_cap,
-                         (const i64*)nullptr, counts, (uint32_t*)nullptr);
+                         (const i64*)nullptr, counts, (uint32_t*)nullptr, flagsB ? (const u64*)nullptr : (const u64*)hist,
+                         innerprod, (const int32_t*)scalars, valued);
   } else {
-    hipLaunchKernelGGL(colsum_nu_kernel, dim3(gridN), dim3(OCN_BLOCK), 0, st, (const u64*)hist, (i64)N, counts);
+    hipLaunchKernelGGL((colsum_nu_kernel<false>), dim3(gridN), dim3(OCN_BLOCK), 0, st, (const u64*)hist, (i64)N, innerprod,
+                       (const int32_t*)scalars, valued, counts);
   }
   rc = ocn_scan_i32(counts, N, (int64_t*)col_off, scan_ws, stream);
   if (rc) return rc;
@@ -268,7 +304,7 @@ int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64
   if (B > 0)
     hipLaunchKernelGGL((colsum_entries_kernel<true>), dim3(gridB), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA, colA,
                        (const i64*)src, (i64)B, (const i64*)off, flagsA, flagsB, (i64)flags_cap, (const i64*)col_off,
-                       counts, entries);
+                       counts, entries, (const u64*)nullptr, innerprod, (const int32_t*)scalars, valued);
   ColCtx cx{flagsA, flagsB, wc, 0.0f};
   hipLaunchKernelGGL(colsum_short_kernel, dim3(grid_for((N + OCN_WPB - 1) / OCN_WPB, 1 << 15)), dim3(OCN_BLOCK), 0, st,
                      (const u64*)hist, (i64)N, (const i64*)col_off, (const uint32_t*)entries, cx, innerprod,
