@@ -13,9 +13,11 @@
 
 #define CS_WAVE_MAX 64          /* columns with at most this many entries: one wave each */
 #ifndef OCN_X_CS_LDS
-#define OCN_X_CS_LDS 8192       /* longer columns up to this many entries are sorted in LDS, beyond in place in memory */
+#define OCN_X_CS_LDS 4096       /* longer columns up to this many entries are sorted in LDS, beyond in place in memory */
 #endif
 #define CS_CHUNK 2048           /* values staged in LDS per accumulation round of a long column */
+#define CS_BINS 256             /* long columns: one bucket pass by position range, then every thread sorts one small bucket */
+#define CS_BIN_MAX 48           /* ... unless a bucket is longer than this (clustered positions): then the bitonic network */
 
 // ---------------------------------------------------------------------------------------------
 // entry lists
@@ -27,15 +29,28 @@ __device__ __forceinline__ bool cs_ordered(u64 pk, u64 walks, float nip, bool va
   return t != 0.0f || (valued ? walks : (u64)hf_n2(pk)) >= (1ull << 24);
 }
 
-// ALL: every column of the union is ordered (cn6)
-template <bool ALL>
-__global__ __launch_bounds__(OCN_BLOCK) void colsum_nu_kernel(const u64* __restrict__ hist, i64 N, const float* __restrict__ innerprod,
-                                                              const int32_t* __restrict__ scalars, int valued,
-                                                              int32_t* __restrict__ counts) {
+// One thread per column: which columns need an ordered sum.  FROM_HIST: counts[c] = the histogram's n_union for an ordered
+// column, 0 otherwise (else: counts come from the counting pass).  An unordered, touched column gets its exact closed
+// form right here; an ordered column without a local entry (an edge shard) passes the earlier shards' partial sum
+// through.  ALL: every column of the union is ordered (cn6).  (A compacted list of the ordered columns for the short
+// kernel was tried: its appends — one atomic per wave on one counter — cost 40 us and saved nothing, the short kernel's
+// time is the ordered columns' own load chains.)
+template <bool FROM_HIST, bool ALL>
+__global__ __launch_bounds__(OCN_BLOCK) void colsum_classify_kernel(const u64* __restrict__ hist, i64 N, const float* __restrict__ innerprod,
+                                                                    const int32_t* __restrict__ scalars, int valued,
+                                                                    int32_t* __restrict__ counts, float* __restrict__ s2,
+                                                                    const float* __restrict__ s2_init) {
   const float nip = cn5_nip(scalars[0], innerprod[0]);
   for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (i64)gridDim.x * blockDim.x) {
-    const u64 pk = hist[2 * c];
-    counts[c] = (ALL || cs_ordered(pk, hist[2 * c + 1], nip, valued)) ? hf_nu(pk) : 0;
+    const u64 pk = hist[2 * c], walks = hist[2 * c + 1];
+    const bool ordered = ALL || cs_ordered(pk, walks, nip, valued);
+    int n;
+    if (FROM_HIST) { n = ordered ? hf_nu(pk) : 0; counts[c] = n; }
+    else n = counts[c];
+    if (n == 0) {
+      if (!ALL && pk != 0 && !ordered) s2[c] = valued ? (float)walks : (float)hf_n2(pk);
+      else if (s2_init) s2[c] = s2_init[c];
+    }
   }
 }
 
@@ -122,16 +137,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void colsum_short_kernel(
   for (i64 c = (i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6); c < N; c += (i64)gridDim.x * OCN_WPB) {
     const i64 b = col_off[c];
     const int n = (int)(col_off[c + 1] - b);
-    if (n == 0) {
-      // no list: an unordered column — its sum is the integer count itself (every rank holds the global histogram) —
-      // or, on an edge shard, an ordered column without an entry here: the earlier shards' partial sum passes through
-      if (lane == 0) {
-        const u64 pk = hist[2 * c], walks = hist[2 * c + 1];
-        if (pk != 0 && !s3 && !cs_ordered(pk, walks, cx.nip, cx.wc != nullptr)) s2[c] = cx.wc ? (float)walks : (float)hf_n2(pk);
-        else if (s2_init) s2[c] = s2_init[c];
-      }
-      continue;
-    }
+    if (n == 0) continue;                                // an unordered or untouched column: colsum_classify_kernel's
     if (n > CS_WAVE_MAX) {
       if (lane == 0) long_list[atomicAdd(n_long, 1)] = (int32_t)c;
       continue;
@@ -192,8 +198,12 @@ __global__ __launch_bounds__(OCN_BLOCK) void colsum_long_kernel(
     const u64* __restrict__ hist, const i64* __restrict__ col_off, uint32_t* __restrict__ entries,
     ColCtx cx, const float* __restrict__ innerprod, const int32_t* __restrict__ scalars,
     float* __restrict__ s2, float* __restrict__ s3, const int32_t* __restrict__ long_list,
-    const int32_t* __restrict__ n_long, int32_t* __restrict__ ticket, const float* __restrict__ s2_init) {
+    const int32_t* __restrict__ n_long, int32_t* __restrict__ ticket, const float* __restrict__ s2_init, i64 cap) {
   __shared__ uint32_t s_key[OCN_X_CS_LDS];
+  __shared__ uint32_t s_out[OCN_X_CS_LDS];
+  __shared__ int s_cnt[CS_BINS], s_start[CS_BINS];
+  __shared__ i64 s_scan[2 * OCN_WPB];
+  __shared__ int s_big;
   __shared__ float s_val[CS_CHUNK];
   __shared__ int s_item;
   __shared__ float s_inv2;
@@ -210,10 +220,44 @@ __global__ __launch_bounds__(OCN_BLOCK) void colsum_long_kernel(
     const int n = (int)(col_off[c + 1] - b);
     uint32_t* keys = entries + b;
     const bool in_lds = n <= OCN_X_CS_LDS;
+    const uint32_t* sorted = keys;                         // where the sorted positions end up
     if (in_lds) {
+      // A column's entries come from all over the batch, so their flag positions spread over [0, cap): CS_BINS position
+      // ranges hold a handful of entries each.  Count, scan, scatter, then thread t insertion-sorts bucket t — four
+      // barriers where the bitonic network of this size needs fifty.
       for (int q = threadIdx.x; q < n; q += OCN_BLOCK) s_key[q] = keys[q];
+      if (threadIdx.x < CS_BINS) s_cnt[threadIdx.x] = 0;
+      if (threadIdx.x == 0) s_big = 0;
       __syncthreads();
-      wg_sort(&s_key[0], n);
+      for (int q = threadIdx.x; q < n; q += OCN_BLOCK) atomicAdd(&s_cnt[(int)(((u64)s_key[q] * CS_BINS) / (u64)cap)], 1);
+      __syncthreads();
+      const int mine = threadIdx.x < CS_BINS ? s_cnt[threadIdx.x] : 0;
+      if (mine > CS_BIN_MAX) s_big = 1;
+      i64 tot;
+      const i64 start = block_excl_scan((i64)mine, s_scan, &tot);
+      if (threadIdx.x < CS_BINS) { s_start[threadIdx.x] = (int)start; s_cnt[threadIdx.x] = (int)start; }
+      __syncthreads();
+      if (!s_big) {
+        for (int q = threadIdx.x; q < n; q += OCN_BLOCK) {
+          const uint32_t k = s_key[q];
+          s_out[atomicAdd(&s_cnt[(int)(((u64)k * CS_BINS) / (u64)cap)], 1)] = k;
+        }
+        __syncthreads();
+        if (threadIdx.x < CS_BINS) {
+          const int lo = s_start[threadIdx.x], hi = lo + mine;
+          for (int i = lo + 1; i < hi; ++i) {
+            const uint32_t k = s_out[i];
+            int j = i - 1;
+            while (j >= lo && s_out[j] > k) { s_out[j + 1] = s_out[j]; --j; }
+            s_out[j + 1] = k;
+          }
+        }
+        __syncthreads();
+        sorted = &s_out[0];
+      } else {
+        wg_sort(&s_key[0], n);
+        sorted = &s_key[0];
+      }
     } else {
       wg_sort(keys, n);
     }
@@ -224,7 +268,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void colsum_long_kernel(
       for (int q0 = 0; q0 < n; q0 += CS_CHUNK) {
         const int m = n - q0 < CS_CHUNK ? n - q0 : CS_CHUNK;
         for (int q = threadIdx.x; q < m; q += OCN_BLOCK) {
-          const uint32_t p = in_lds ? s_key[q0 + q] : keys[q0 + q];
+          const uint32_t p = sorted[q0 + q];
           bool in2;
           float a3, tt;
           const float v2 = entry_v2(cx, p, t, in2, a3, tt);
@@ -287,6 +331,9 @@ int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64
   if (rc) return rc;
   hipLaunchKernelGGL(colsum_zero_kernel, dim3(1), dim3(OCN_BLOCK), 0, st, tickets, (i64)(4 + sw / 4));   // + the scan state
   const int valued = wc != nullptr;
+#define CLASSIFY(FROM_HIST, ALL)                                                                                          \
+  hipLaunchKernelGGL((colsum_classify_kernel<FROM_HIST, ALL>), dim3(gridN), dim3(OCN_BLOCK), 0, st, (const u64*)hist, (i64)N, \
+                     innerprod, (const int32_t*)scalars, valued, counts, s2, s2_init)
   if (flagsB || s2_init) {        // cn6: the union is wider than histA's n_union; a shard: hist holds the GLOBAL counts
     hipLaunchKernelGGL(colsum_zero_kernel, dim3(gridN), dim3(OCN_BLOCK), 0, st, counts, (i64)N);
     if (B > 0)
@@ -294,10 +341,11 @@ int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64
                          (const i64*)src, (i64)B, (const i64*)off, flagsA, flagsB, (i64)flags_cap,
                          (const i64*)nullptr, counts, (uint32_t*)nullptr, flagsB ? (const u64*)nullptr : (const u64*)hist,
                          innerprod, (const int32_t*)scalars, valued);
+    if (flagsB) CLASSIFY(false, true); else CLASSIFY(false, false);
   } else {
-    hipLaunchKernelGGL((colsum_nu_kernel<false>), dim3(gridN), dim3(OCN_BLOCK), 0, st, (const u64*)hist, (i64)N, innerprod,
-                       (const int32_t*)scalars, valued, counts);
+    CLASSIFY(true, false);
   }
+#undef CLASSIFY
   rc = ocn_scan_i32(counts, N, (int64_t*)col_off, scan_ws, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(colsum_zero_kernel, dim3(gridN), dim3(OCN_BLOCK), 0, st, counts, (i64)N);
@@ -309,9 +357,9 @@ int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64
   hipLaunchKernelGGL(colsum_short_kernel, dim3(grid_for((N + OCN_WPB - 1) / OCN_WPB, 1 << 15)), dim3(OCN_BLOCK), 0, st,
                      (const u64*)hist, (i64)N, (const i64*)col_off, (const uint32_t*)entries, cx, innerprod,
                      (const int32_t*)scalars, s2, s3, long_list, tickets, s2_init);
-  hipLaunchKernelGGL(colsum_long_kernel, dim3(256 * 2), dim3(OCN_BLOCK), 0, st, (const u64*)hist, (const i64*)col_off,
+  hipLaunchKernelGGL(colsum_long_kernel, dim3(256 * 3), dim3(OCN_BLOCK), 0, st, (const u64*)hist, (const i64*)col_off,
                      entries, cx, innerprod, (const int32_t*)scalars, s2, s3, (const int32_t*)long_list,
-                     (const int32_t*)tickets, tickets + 1, s2_init);
+                     (const int32_t*)tickets, tickets + 1, s2_init, (i64)(flags_cap > 0 ? flags_cap : 1));
   return launch_status();
 }
 
