@@ -116,6 +116,8 @@ int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, vo
  * rec (or NULL): per processing SLOT a 32-byte record {batch row, src | dst << 32, start of N(src) | length << 40,
  * off | (cnt1 > 0) << 62 | (cnt2 > 0) << 63}: ocn_cn_gather given the same `rec` reads it instead of walking
  * order -> src / dst / off / counts -> rowptr (one dependent load in front of its first gather instead of three).
+ * gcost (or NULL): int32[ceil(B / 4)]: per group of four consecutive processing slots the number of cn1 + cn2 entries
+ * its candidates have — what the group will cost the pooling; see ocn_gather_schedule.
  * bitmapT1: the same for T1 (ocn_bitrows_from_csr; small dense graphs); rowptrT1 / colT1 may then be NULL.
  * status: device int32, bit 0 set if off[B] > flags_cap (nothing is written past the cap).
  * order (here and below): optional permutation of 0..B-1 giving the order in which the batch rows
@@ -129,7 +131,7 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA,
                  const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                  int64_t n_cols, const int64_t* off, uint8_t* flags, int64_t flags_cap,
                  uint64_t* hist /* [n_cols][2] */, int32_t* cnt1, int32_t* cnt2,
-                 int32_t* status, uint64_t* rec /* [B][4] or NULL */, void* stream);
+                 int32_t* status, uint64_t* rec /* [B][4] or NULL */, int32_t* gcost /* [ceil(B/4)] or NULL */, void* stream);
 
 /* The pygho route get_cn1_cn2 (NeighborOverlap_large_ppa.py:147-173, NeighborOverlapCitation2.py:
  * 78-104) without forming Ej·A: cn1 = N(i) ∩ N(j) as above; cn2[e,k] = |N(k) ∩ N(j)| (number of
@@ -244,7 +246,13 @@ int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA,
                   const int64_t* off, const uint8_t* flags, const int32_t* wc,
                   const float* weights /* [N][4] */, const float* h, int32_t H, int64_t max_row_len,
                   float* xcn1, float* xcn2, float* xij, const int64_t* out_row,
-                  const int32_t* cnt1, const int32_t* cnt2, const uint64_t* rec /* or NULL */, void* stream);
+                  const int32_t* cnt1, const int32_t* cnt2, const uint64_t* rec /* or NULL */,
+                  const int32_t* perm /* ocn_gather_schedule's, or NULL */, void* stream);
+/* The pooling's visiting order at H = 256 (a workgroup = four candidates = one group of ocn_cn_flags' gcost): candidates
+ * differ 100x in cost and the few with hundreds of rows, met late, end the kernel as stragglers (0.206 -> 0.17 ms at the
+ * collab shape).  perm[] = inside each XCD's contiguous eighth of the groups, the groups stable-sorted by descending cost:
+ * groups of one source keep one cost and stay neighbours (L2).  n_groups = B / 4, a multiple of 8, at most 8 * 65535. */
+int ocn_gather_schedule(const int32_t* gcost, int64_t n_groups, int32_t* perm, void* stream);
 
 /* The 3-hop predictor cn6 (model.py:2535-2951), pattern route.  Two intersection passes over the same
  * candidate batch — (A, A, A²) into flagsA / histA and (A, A³) into flagsB / histB (bit 0 = cn3 entry,

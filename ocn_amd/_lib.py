@@ -33,7 +33,7 @@ SIGNATURES = {
     "ocn_order_by_node_finish": (c_int32, [_P, c_int64, c_int64, _P, _P, _P]),
     "ocn_batch_prep": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, _P, c_int32, _P]),
     "ocn_cn_flags": (c_int32, [_P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int64, _P, _P, c_int64, _P,
-                               _P, _P, _P, _P, _P]),
+                               _P, _P, _P, _P, _P, _P]),
     "ocn_chunk_offsets": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P]),
     "ocn_walk_chunk": (c_int32, []),
     "ocn_cn_walk_flags": (c_int32, [_P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, c_int64, _P, _P, _P,
@@ -49,7 +49,8 @@ SIGNATURES = {
     "ocn_cn_colsum_exact": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "ocn_cn_weights_cn7": (c_int32, [_P, c_int64, c_float, _P]),
     "ocn_cn_gather": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P, _P,
-                                _P, _P, _P]),
+                                _P, _P, _P, _P]),
+    "ocn_gather_schedule": (c_int32, [_P, c_int64, _P, _P]),
     "ocn_cn_weights_cn6": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "ocn_cn_gather3": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),
     "ocn_cn_gather_backward": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),

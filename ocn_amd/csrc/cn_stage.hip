@@ -44,6 +44,14 @@ __device__ __forceinline__ bool sampled_has(const int32_t* samp, const int32_t* 
 #ifndef OCN_X_G
 #define OCN_X_G 64     /* lanes per candidate edge; tools/kbench.py overrides it for timing experiments */
 #endif
+// a group's cost: the largest entry count among its four candidates (a wave walks one candidate), in buckets of 32 —
+// measured at the collab shape (tools/_ab notes in DESIGN.md): sum / max and 4 .. 256-entry buckets all land within
+// 0.184 - 0.200 ms against 0.206 unscheduled; coarse buckets keep more of the source order's L2 locality
+#define SCHED_COST(t, c) ((t) > (c) ? (t) : (c))
+#ifndef OCN_X_SCHED_SHIFT
+#define OCN_X_SCHED_SHIFT 5
+#endif
+#define SCHED_GROUP (OCN_BLOCK / OCN_X_G)    /* slots per scheduling group: a workgroup of the intersection pass == one of the H = 256 pooling */
 
 // G lanes cooperate on one candidate edge (64/G edges per wave).  Measured on the collab-shaped
 // batch (tools/kbench.py): G = 64 / 32 / 16 / 8 -> 208 / 242 / 327 / 494 us.  The kernel is bound by
@@ -64,8 +72,9 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
     i64 n_cols, const i64* __restrict__ off, uint8_t* __restrict__ flags, i64 cap,
     u64* __restrict__ hist, int32_t* __restrict__ cnt1, int32_t* __restrict__ cnt2,
-    int32_t* __restrict__ status, u64* __restrict__ rec) {
+    int32_t* __restrict__ status, u64* __restrict__ rec, int32_t* __restrict__ gcost) {
   constexpr int GPB = OCN_BLOCK / G;
+  __shared__ int s_cost[GPB];
   __shared__ int32_t s_t1[GPB][T1_CAP];
   __shared__ int32_t s_t2[GPB][OCN_WAVE];
   extern __shared__ __attribute__((aligned(16))) u64 s_hist[];      // LH only: n_cols words
@@ -154,6 +163,18 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
         r[1] = (u64)i | ((u64)j << 32);
         r[2] = (u64)a0 | ((u64)da << REC_LEN_SHIFT);
         r[3] = (u64)base | ((u64)(c1 > 0) << 62) | ((u64)(c2 > 0) << 63);
+      }
+    }
+    if (gcost) {
+      // what this group of GPB consecutive slots will cost the pooling (entries to gather): the pooling visits its
+      // groups longest first (ocn_gather_schedule), so that no straggler ends its kernel
+      if (gl == 0) s_cost[g] = act ? c1 + c2 : 0;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int t = 0;
+#pragma unroll
+        for (int q = 0; q < GPB; ++q) t = SCHED_COST(t, s_cost[q]);
+        gcost[e0 / GPB] = t;
       }
     }
     __syncthreads();
@@ -744,7 +765,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
     float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij,
     const i64* __restrict__ out_row,     // out_row[batch row] = output row (class-major heads), or NULL
     const int32_t* __restrict__ cnt1, const int32_t* __restrict__ cnt2,     // per-row CN counts, or NULL
-    const u64* __restrict__ rec) {       // slot records of the intersection pass (then order/src/dst/off/cnt are not read), or NULL
+    const u64* __restrict__ rec,         // slot records of the intersection pass (then order/src/dst/off/cnt are not read), or NULL
+    const int32_t* __restrict__ perm) {  // ocn_gather_schedule's visiting order of the slot groups (longest first per XCD), or NULL
   constexpr int GPW = OCN_WAVE / LPE;
   const int lane = threadIdx.x & 63;
   const int gl = lane % LPE;
@@ -759,7 +781,12 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
     bid >>= 3;
   } else {
 #ifndef OCN_X_NOXCD
-    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    if ((gridDim.x & 7) == 0) {
+      bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+      // ... and inside its eighth an XCD takes the groups in the order of the schedule: the longest jobs first (groups of
+      // one source have one cost and stay neighbours: the L2 locality of the source order is kept)
+      if (perm) bid = perm[bid];
+    }
 #endif
   }
   const i64 slot = (bid * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
@@ -1313,8 +1340,10 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
                           const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
                           const int32_t* wc, const float* weights, const float* h, int32_t H, int64_t max_row_len,
                           float* xcn1, float* xcn2, float* xij, const int64_t* out_row, const int32_t* cnt1,
-                          const int32_t* cnt2, const uint64_t* rec, hipStream_t st) {
+                          const int32_t* cnt2, const uint64_t* rec, const int32_t* perm, hipStream_t st) {
   const i64 epb = (i64)OCN_WPB * (OCN_WAVE / LPE);
+  // the schedule's groups are the workgroups of the intersection pass: usable where the pooling's workgroups are the same
+  const bool sched = perm && rec && epb == SCHED_GROUP && ((B + epb - 1) / epb) % 8 == 0;
   bool packed = true;
   if constexpr (LPE <= 16) {
     if (B * LPE < 262144) {                  // the packed form would not fill the SIMDs
@@ -1338,14 +1367,14 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
       const i64 spb = (i64)OCN_WPB * (OCN_WAVE / SL);
       if (B >= GATHER_SLICE_MIN_BATCH) {
         hipLaunchKernelGGL((cn_gather_kernel<SL, 1, true>), dim3((unsigned)(8 * ((B + spb - 1) / spb))), dim3(OCN_BLOCK),
-                           0, st, PACKED_ARGS);
+                           0, st, PACKED_ARGS, (const int32_t*)nullptr);
         sliced = true;
       }
     }
 #endif
     if (!sliced)
       hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)), dim3(OCN_BLOCK), 0, st,
-                         PACKED_ARGS);
+                         PACKED_ARGS, sched ? perm : (const int32_t*)nullptr);
   }
 #undef PACKED_ARGS
 #define LONG_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, wc, \
@@ -1381,7 +1410,7 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
                  const uint32_t* bitmapT1, int64_t bm1_stride_words, const uint32_t* bitmapT2, int64_t bm_stride_words,
                  const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                  int64_t n_cols, const int64_t* off, uint8_t* flags, int64_t flags_cap, uint64_t* hist,
-                 int32_t* cnt1, int32_t* cnt2, int32_t* status, uint64_t* rec, void* stream) {
+                 int32_t* cnt1, int32_t* cnt2, int32_t* status, uint64_t* rec, int32_t* gcost, void* stream) {
   if (B < 0 || flags_cap < 0 || B > (int64_t)HF_MASK) return OCN_EINVAL;
   if (B == 0) return 0;
   if (!rowptrA || (!rowptrT1 && !bitmapT1) || !src || !dst || !off || !hist || !cnt1 || !status) return OCN_EINVAL;
@@ -1414,7 +1443,7 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
   (const i64*)rowptrA, colA, (const i64*)rowptrT1, colT1, (const i64*)(T2P), (T2C),                   \
       (const unsigned*)bitmapT1, (i64)bm1_stride_words, (const unsigned*)bitmapT2, (i64)bm_stride_words, (const i64*)src, \
       (const i64*)dst, (const i64*)order, (i64)B, (i64)n_cols, (const i64*)off, flags, (i64)flags_cap, \
-      (u64*)hist, cnt1, cnt2, status, (u64*)rec
+      (u64*)hist, cnt1, cnt2, status, (u64*)rec, gcost
   if (rowptrT2) {
     if (lh) hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, true, true>), dim3(grid), dim3(OCN_BLOCK), lds, st,
                                CN_FLAGS_ARGS(rowptrT2, colT2));
@@ -1510,13 +1539,63 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream) 
 #define GATHER_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, (const i64*)off, \
                     flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij, (const i64*)out_row
 #define LAUNCH_GATHER(LPE, NV)                                                                      \
-  launch_gather<LPE, NV>(rowptrA, colA, src, dst, order, B, off, flags, wc, weights, h, H, max_row_len, xcn1, xcn2, xij, out_row, cnt1, cnt2, rec, st)
+  launch_gather<LPE, NV>(rowptrA, colA, src, dst, order, B, off, flags, wc, weights, h, H, max_row_len, xcn1, xcn2, xij, out_row, cnt1, cnt2, rec, perm, st)
+
+// The visiting order of the pooling's slot groups: each XCD's contiguous eighth of the groups, stable-sorted by
+// descending cost (64 buckets) — one workgroup per eighth, a counting sort in LDS: thread t counts the
+// buckets of its contiguous share, the bucket-major table of counts is scanned, and the second pass writes every group
+// to its rank.  Stable: groups of one source (one cost) stay neighbours.
+#define SCHED_BUCKETS 64
+__global__ __launch_bounds__(OCN_BLOCK) void gather_schedule_kernel(const int32_t* __restrict__ gcost, i64 n_groups,
+                                                                    int32_t* __restrict__ perm) {
+  __shared__ unsigned short tc[SCHED_BUCKETS * OCN_BLOCK];
+  __shared__ i64 s_scan[2 * OCN_WPB];
+  const int t = threadIdx.x;
+  const i64 per = n_groups >> 3, lo = (i64)blockIdx.x * per;                  // (n_groups is a multiple of 8)
+  const i64 ipt = (per + OCN_BLOCK - 1) / OCN_BLOCK;                          // groups per thread, contiguous
+  for (int b = 0; b < SCHED_BUCKETS; ++b) tc[b * OCN_BLOCK + t] = 0;
+  auto bucket = [&](i64 q) -> int {
+    const int c = gcost[lo + q] >> OCN_X_SCHED_SHIFT;
+    return SCHED_BUCKETS - 1 - (c < SCHED_BUCKETS - 1 ? c : SCHED_BUCKETS - 1);
+  };
+  for (i64 k = 0; k < ipt; ++k) {
+    const i64 q = (i64)t * ipt + k;
+    if (q < per) tc[bucket(q) * OCN_BLOCK + t] += 1;
+  }
+  __syncthreads();
+  // exclusive scan of the flattened table (bucket-major, then thread): thread t owns entries [64 t, 64 t + 64)
+  i64 mine = 0;
+  for (int q = 0; q < SCHED_BUCKETS; ++q) mine += tc[t * SCHED_BUCKETS + q];
+  i64 tot;
+  i64 run = block_excl_scan(mine, s_scan, &tot);
+  for (int q = 0; q < SCHED_BUCKETS; ++q) {
+    const int v = tc[t * SCHED_BUCKETS + q];
+    tc[t * SCHED_BUCKETS + q] = (unsigned short)run;
+    run += v;
+  }
+  __syncthreads();
+  for (i64 k = 0; k < ipt; ++k) {
+    const i64 q = (i64)t * ipt + k;
+    if (q < per) {
+      const int b = bucket(q);
+      perm[lo + tc[b * OCN_BLOCK + t]++] = (int32_t)(lo + q);
+    }
+  }
+}
+
+int ocn_gather_schedule(const int32_t* gcost, int64_t n_groups, int32_t* perm, void* stream) {
+  if (n_groups < 0 || (n_groups & 7) || (n_groups >> 3) > 65535) return OCN_EINVAL;      // eighths; ranks are 16-bit
+  if (n_groups == 0) return 0;
+  if (!gcost || !perm) return OCN_EINVAL;
+  hipLaunchKernelGGL(gather_schedule_kernel, dim3(8), dim3(OCN_BLOCK), 0, (hipStream_t)stream, gcost, (i64)n_groups, perm);
+  return launch_status();
+}
 
 int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* src,
                   const int64_t* dst, const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
                   const int32_t* wc, const float* weights, const float* h, int32_t H,
                   int64_t max_row_len, float* xcn1, float* xcn2, float* xij, const int64_t* out_row,
-                  const int32_t* cnt1, const int32_t* cnt2, const uint64_t* rec, void* stream) {
+                  const int32_t* cnt1, const int32_t* cnt2, const uint64_t* rec, const int32_t* perm, void* stream) {
   if (B < 0 || H <= 0) return OCN_EINVAL;
   if (B == 0) return 0;
   if (!rowptrA || !src || !dst || !off || !weights || !h || !xcn1 || !xcn2 || !xij) return OCN_EINVAL;

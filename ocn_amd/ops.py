@@ -28,6 +28,7 @@ skip_zero_min_batch = 4096       # below this the extra small launches cost more
 walk_two_sided = True            # walk route: sweep each candidate from its cheaper endpoint (needs nds of the adjacency)
 walk_share_min = 2               # walk route, B <= 4096: candidates sharing a source are swept together from this group size on (0 = never)
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
+heavy_first = True               # ... and the pooling (H = 256) visits its slot groups longest first (ocn_cn_flags' gcost -> ocn_gather_schedule)
 
 
 def _on_device(fn):
@@ -187,7 +188,7 @@ def hist_counts(hist: Tensor) -> Tensor:
 def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
              t2: Optional[Tuple[Tensor, Tensor]], src: Tensor, dst: Tensor, n_cols: int, max_deg_a: int,
              walk: bool = False, t2_bitmap: Optional[Tensor] = None, wsd=None, nds: Optional[Tensor] = None,
-             t1_bitmap: Optional[Tensor] = None, rec: Optional[Tensor] = None):
+             t1_bitmap: Optional[Tensor] = None, rec: Optional[Tensor] = None, sched: Optional[Tensor] = None):
     """Intersection pass.  ``walk=False``: flags of N(src) against the rows of dst in t1 (and t2).
     ``walk=True``: the pygho route on A itself (t1/t2 ignored): cn1 flags + walk counts; with ``nds``
     (``neighbor_degree_sum`` of A) every batch row is swept from its cheaper endpoint.
@@ -226,6 +227,9 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     scal = buf(wsd, "scal", 4, torch.int32, dev)         # the column statistics word of the weights stage
     # the flag offsets, the counting phase of the order and the batch's resets: ONE launch (ocn_batch_prep)
     zs = [t for t in [hist, status, scal] + ([cnt1, cnt2] if walk else []) if t is not None and t.numel()]
+    if sched is not None:             # group costs for the pooling's schedule (ocn_hip.h: ocn_cn_flags `gcost`): first half of `sched`
+        if rec is None or walk or _req(sched, torch.int32, "sched", 1).numel() < 2 * ((B + 3) // 4):
+            raise ValueError("sched: int32[2 * ceil(B / 4)] beside the slot records of the pattern route")
     zp = (ctypes.c_void_p * len(zs))(*[t.data_ptr() for t in zs])
     zb = (ctypes.c_int64 * len(zs))(*[t.numel() * t.element_size() for t in zs])
     check(_lib.lib().ocn_batch_prep(ptr(rowptrA), ptr(src), B, ptr(off), ptr(sws), n_src, ptr(ows), zp, zb, len(zs),
@@ -273,7 +277,7 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
                                       ptr(t1_bitmap), t1_bitmap.shape[1] if t1_bitmap is not None else 0,
                                       ptr(t2_bitmap), t2_bitmap.shape[1] if t2_bitmap is not None else 0,
                                       ptr(src), ptr(dst), ptr(order), B, n_cols, ptr(off), ptr(flags), cap, ptr(hist),
-                                      ptr(cnt1), ptr(cnt2), ptr(status), ptr(rec), stream_ptr()), "ocn_cn_flags")
+                                      ptr(cnt1), ptr(cnt2), ptr(status), ptr(rec), ptr(sched), stream_ptr()), "ocn_cn_flags")
     _mark("cn_flags")
     return order, off, flags, wc, hist, cnt1, cnt2, status, scal
 
@@ -411,16 +415,23 @@ def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
 @_on_device
 def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights: Tensor, h: Tensor,
               order: Optional[Tensor] = None, max_row_len: int = 0, wsd=None, out_row: Optional[Tensor] = None,
-              cnt1: Optional[Tensor] = None, cnt2: Optional[Tensor] = None, rec: Optional[Tensor] = None):
+              cnt1: Optional[Tensor] = None, cnt2: Optional[Tensor] = None, rec: Optional[Tensor] = None,
+              sched: Optional[Tensor] = None):
     _req(weights, torch.float32, "weights", 2)
     _req(h, torch.float32, "h", 2)
     if weights.shape[0] != h.shape[0] or weights.shape[1] != 4:
         raise ValueError("weights must be [N,4] with N = h.shape[0]")
     B, H = src.numel(), h.shape[1]
     out = buf(wsd, "pooled", (3, B, H), torch.float32, h.device)
+    perm = None
+    if sched is not None and rec is not None and H == 256 and B % 32 == 0 and B // 32 <= 65535:
+        n_groups = B // 4             # the intersection pass left the groups' costs in sched[:n_groups]; their visiting order follows
+        perm = sched[n_groups:]
+        check(_lib.lib().ocn_gather_schedule(ptr(sched), n_groups, ptr(perm), stream_ptr()), "ocn_gather_schedule")
     check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags),
                                    ptr(wc), ptr(weights), ptr(h), H, int(max_row_len), ptr(out[0]), ptr(out[1]),
-                                   ptr(out[2]), ptr(out_row), ptr(cnt1), ptr(cnt2), ptr(rec), stream_ptr()), "ocn_cn_gather")
+                                   ptr(out[2]), ptr(out_row), ptr(cnt1), ptr(cnt2), ptr(rec), ptr(perm),
+                                   stream_ptr()), "ocn_cn_gather")
     _mark("cn_gather")
     return out[0], out[1], out[2]
 

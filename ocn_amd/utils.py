@@ -66,12 +66,15 @@ class CNState:
         ops.check_edges(self.src, self.dst, adj.size(0), adj.size(0) if walk else t1.size(0))
         # per-slot records the intersection pass leaves for the pooling (pattern route)
         self.rec = None if (walk or self.B == 0) else ops.buf(ws, "rec", (self.B, 4), torch.int64, self.src.device)
+        # ... and what each group of four slots will cost the pooling, for its longest-first schedule (+ room for the schedule)
+        self.sched = (ops.buf(ws, "sched", 2 * ((self.B + 3) // 4), torch.int32, self.src.device)
+                      if (self.rec is not None and ops.heavy_first and self.B >= ops.sort_edges_min_batch) else None)
         (self.order, self.off, self.flags, self.wc, self.hist, self.cnt1, self.cnt2, self.status, self.scal) = ops.cn_flags(
             adj._rowptr, adj._col, None if walk else (t1._rowptr, t1._col),
             None if (walk or t2 is None) else (t2._rowptr, t2._col), self.src, self.dst, self.N,
             adj.max_rowcount(), walk=walk, t2_bitmap=None if (walk or t2 is None) else t2._bitmap, wsd=ws,
             nds=adj.neighbor_degree_sum() if (walk and ops.walk_two_sided) else None,
-            t1_bitmap=None if walk else t1.bit_rows(), rec=self.rec)
+            t1_bitmap=None if walk else t1.bit_rows(), rec=self.rec, sched=self.sched)
         self._hist_live = True
 
     @classmethod
@@ -162,7 +165,8 @@ class CNState:
         return ops.cn_gather(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off,
                              self.flags, self.wc, weights, h, order=self.order if order is None else order,
                              max_row_len=self.adj.max_rowcount(), wsd=self.ws, out_row=out_row,
-                             cnt1=self.cnt1, cnt2=self.cnt2, rec=getattr(self, "rec", None) if order is None else None)
+                             cnt1=self.cnt1, cnt2=self.cnt2, rec=getattr(self, "rec", None) if order is None else None,
+                             sched=getattr(self, "sched", None) if order is None else None)
 
     def gather_backward(self, weights: Tensor, h: Tensor, g1: Tensor, g2: Tensor, g3: Tensor) -> Tensor:
         return ops.cn_gather_backward(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off, self.flags,
