@@ -142,7 +142,11 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
 #ifndef OCN_X_NOATOMIC
       if (f1 | f2) {
         const u64 inc = (u64)f1 | ((u64)f2 << HF_BITS) | (1ull << (2 * HF_BITS));
+#ifdef OCN_X_ATOMIC_SPREAD   /* timing experiment: the same number of atomics on uniformly spread addresses (no hot column) */
+        if (LH) atomicAdd(s_hist + k, inc); else atomicAdd(hist + 2 * (i64)((((u64)k * 2654435761ull) ^ ((u64)(base + p) * 40503ull)) % (u64)n_cols), inc);
+#else
         if (LH) atomicAdd(s_hist + k, inc); else atomicAdd(hist + 2 * (i64)k, inc);
+#endif
       }
 #endif
       c1 += f1;
