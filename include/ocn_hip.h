@@ -29,7 +29,7 @@ extern "C" {
  * group entries, dense block route, ocn_heads_fused; 3: ocn_cn_flags takes bit rows of T1, ocn_bitrows_from_csr;
  * 4: ocn_batch_prep, ocn_order_by_node_finish; 5: slot records (`rec`) from ocn_cn_flags to ocn_cn_gather;
  * 6: ocn_heads_fused on f16 hi/lo panels (ocn_heads_split_weight replaces ocn_linear_split_weight_chained). */
-#define OCN_ABI_VERSION 6
+#define OCN_ABI_VERSION 7
 #define OCN_EINVAL (-1)   /* null pointer / negative size / unsupported combination */
 #define OCN_ECAP   (-2)   /* reported through the device status word: flags capacity too small */
 
@@ -282,6 +282,16 @@ int ocn_cn_gather_backward(const int64_t* rowptrA, const int32_t* colA,
                            const float* weights, const float* h, int32_t H,
                            const float* g1, const float* g2, const float* g3, float* dh, void* stream);
 
+/* The same gradient without float atomics (the default of the Python layer): the batch's terms are transposed into
+ * per-node lists (count -> scan -> fill -> per-list sort by flag position; the two endpoint terms of a candidate follow)
+ * and ONE wave per node adds its list in that order — the same bits on every run.  dh [N][H] is read and written (the
+ * caller initialises it); H a multiple of 4, <= 512; flags_cap + 2 B < 2^31. */
+int64_t ocn_cn_gather_backward_det_workspace_bytes(int64_t N, int64_t B, int64_t flags_cap);
+int ocn_cn_gather_backward_det(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
+                               int64_t B, const int64_t* off, const uint8_t* flags, const int32_t* wc, int64_t flags_cap,
+                               const float* weights, const float* h, int64_t N, int32_t H, const float* g1,
+                               const float* g2, const float* g3, float* dh, void* workspace, void* stream);
+
 /* CSR SpMM of the encoders: torch_sparse spmm_add/mean/max (model.py:42-55), PyG GCNConv
  * propagate (model.py:58-68), pygho/torch COO @ dense (model.py:105-113).
  *   y[r] = post[r] * reduce_k( pre[r]^a * pre[k] * x[k] )  (+ self term)
@@ -437,6 +447,26 @@ int64_t ocn_heads_const_bytes(int32_t H);
 int64_t ocn_heads_panel_bytes(int32_t N, int32_t K);
 int ocn_heads_split_weight(const float* W, int32_t N, int32_t K, float scale, void* Wp, void* stream);
 int ocn_heads_fused(const OcnHeadsArgs* args, void* stream);
+
+/* Training-side pieces (NeighborOverlap_large.py:56-63, 76-90).
+ *
+ * ocn_coo_to_csr: the per-batch masked adjacency — SparseTensor.from_edge_index(tei, sparse_sizes) (a sort by (row, col)
+ * in torch_sparse; dedupe = 0: duplicates are kept, as there) and .to_symmetric() (symmetrize = 1, dedupe = 1: the
+ * transposed entries join and the pattern is coalesced), pattern only.  Count -> scan -> fill -> per-row sort (wave rank
+ * sort / workgroup bitonic network) -> unique count -> scan -> compact, all on `stream`.  rowptr [n_rows + 1]; col_out must
+ * hold nnz * (symmetrize ? 2 : 1) entries (the upper bound); result[0] = entries written (= rowptr[n_rows]), result[1] = 1
+ * if an index was out of range (such entries are dropped) — device memory, the caller reads it when it needs to. */
+int64_t ocn_coo_to_csr_workspace_bytes(int64_t nnz, int64_t n_rows, int32_t symmetrize, int32_t dedupe);
+int ocn_coo_to_csr(const int64_t* row, const int64_t* col, int64_t nnz, int64_t n_rows, int64_t n_cols,
+                   int32_t symmetrize, int32_t dedupe, int64_t* rowptr, int32_t* col_out, void* workspace,
+                   int64_t* result, void* stream);
+
+/* ocn_wgrad: weight / bias gradient of a Linear layer, dW[N][K] = dY^T X, db[N] = column sums of dY (db may be NULL),
+ * dY [B][N] row stride ldY, X [B][K] row stride ldX, fp32.  bf16x6 on the matrix cores, split over the batch; the
+ * slices' partial results are added in slice order (no float atomics: the same bits on every run).  Any N, K >= 1. */
+int64_t ocn_wgrad_workspace_bytes(int64_t B, int32_t N, int32_t K);
+int ocn_wgrad(const float* dY, int64_t ldY, const float* X, int64_t ldX, int64_t B, int32_t N, int32_t K,
+              float* dW, float* db, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -19,7 +19,7 @@ INCLUDE = os.path.join(_ROOT, "include")
 
 # name -> (restype, argtypes); must list every symbol include/ocn_hip.h declares
 _P = c_void_p
-ABI_VERSION = 6
+ABI_VERSION = 7
 SIGNATURES = {
     "ocn_abi_version": (c_int32, []),
     "ocn_scan_workspace_bytes": (c_int64, [c_int64]),
@@ -51,9 +51,16 @@ SIGNATURES = {
     "ocn_cn_gather": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P, _P,
                                 _P, _P, _P, _P]),
     "ocn_gather_schedule": (c_int32, [_P, c_int64, _P, _P]),
+    "ocn_coo_to_csr_workspace_bytes": (c_int64, [c_int64, c_int64, c_int32, c_int32]),
+    "ocn_coo_to_csr": (c_int32, [_P, _P, c_int64, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
+    "ocn_wgrad_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32]),
+    "ocn_wgrad": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "ocn_cn_weights_cn6": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "ocn_cn_gather3": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),
     "ocn_cn_gather_backward": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),
+    "ocn_cn_gather_backward_det_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "ocn_cn_gather_backward_det": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, c_int64, c_int32, _P, _P, _P, _P,
+                                             _P, _P]),
     "ocn_spmm_csr": (c_int32, [_P, _P, _P, c_int64, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "ocn_deg_rsqrt": (c_int32, [_P, _P, c_int64, c_float, _P, _P]),
     "ocn_spgemm_max_cols": (c_int64, []),
@@ -110,8 +117,7 @@ def sources():
 def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
     """Compile csrc/*.hip -> ocn_amd/libocn_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
     out = out or LIB_PATH
-    deps = sources() + [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "ocn_hip.h"),
-                        os.path.abspath(__file__)]
+    deps = sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INCLUDE, "ocn_hip.h"), os.path.abspath(__file__)]
     if not force and not extra_flags and os.path.exists(out) and \
             os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
         return out

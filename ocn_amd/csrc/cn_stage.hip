@@ -626,12 +626,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn7_column_weights(u64* __restrict_
 // ---------------------------------------------------------------------------------------------
 // K3: pooling — gather embedding rows over the flagged neighbours
 // ---------------------------------------------------------------------------------------------
-// per-entry weights from the flag byte, the column's {w1, t, inv2} and the cn2 value c
-__device__ __forceinline__ void entry_weights(unsigned f, const float4& w, float c, float& wa, float& wb) {
-  wa = (f & OCN_F_CN1) ? w.x : 0.f;
-  const float v = __fsub_rn((f & OCN_F_CN2) ? c : 0.f, (f & OCN_F_CN1) ? w.y : 0.f);
-  wb = __fmul_rn(v, w.z);
-}
+// (entry_weights: common.h)
 
 // Pool the flagged neighbours at positions [p_begin, p_end) of the source row into acc1 / acc2, in
 // ascending position (= column) order.  LPE lanes cooperate; each lane owns NV float4 of the

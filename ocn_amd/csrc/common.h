@@ -128,3 +128,29 @@ __device__ __forceinline__ void axpy4(float4& acc, float w, const float4& x) {
   acc.w = __fadd_rn(acc.w, __fmul_rn(w, x.w));
 }
 
+// per-entry pooling weights from the flag byte, the column's {w1, t, inv2} and the cn2 value c (model.py:2380-2427)
+__device__ __forceinline__ void entry_weights(unsigned f, const float4& w, float c, float& wa, float& wb) {
+  wa = (f & OCN_F_CN1) ? w.x : 0.f;
+  const float v = __fsub_rn((f & OCN_F_CN2) ? c : 0.f, (f & OCN_F_CN1) ? w.y : 0.f);
+  wb = __fmul_rn(v, w.z);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fp32 operands on the bf16 matrix pipe (linear.hip, wgrad.hip)
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ float bf16_to_f32(__bf16 v) {
+  return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, v) << 16);
+}
+
+// x = p1 + p2 + p3 (+ O(2^-27 |x|)), each term a bf16 (round to nearest even)
+__device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
+  p1 = (__bf16)x;
+  const float r1 = x - bf16_to_f32(p1);
+  p2 = (__bf16)r1;
+  const float r2 = r1 - bf16_to_f32(p2);
+  p3 = (__bf16)r2;
+}
+

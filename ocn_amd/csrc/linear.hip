@@ -14,27 +14,11 @@
 // fragment-ordered weight panel of each 16-deep k-step is staged in LDS and shared by the 4 waves.
 #include "common.h"
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-
 #define LIN_KS 16                    // k per MFMA step
 #define LIN_ROWS 128                 // rows per workgroup
 #ifndef LIN_PF
 #define LIN_PF 4                     // X fragments in flight per lane (k-steps of look-ahead)
 #endif
-
-__device__ __forceinline__ float bf16_to_f32(__bf16 v) {
-  return __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, v) << 16);
-}
-
-// x = p1 + p2 + p3 (+ O(2^-27 |x|)), each term a bf16 (round to nearest even)
-__device__ __forceinline__ void split3(float x, __bf16& p1, __bf16& p2, __bf16& p3) {
-  p1 = (__bf16)x;
-  const float r1 = x - bf16_to_f32(p1);
-  p2 = (__bf16)r1;
-  const float r2 = r1 - bf16_to_f32(p2);
-  p3 = (__bf16)r2;
-}
 
 __device__ __forceinline__ void split_frag(const float4& xa, const float4& xb, bf16x8& a1, bf16x8& a2, bf16x8& a3) {
   const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};

@@ -418,8 +418,9 @@ def _seq_eval(seq: nn.Sequential, x: Tensor, y_row_map: Optional[Tensor] = None)
 
 class _LinearFn(torch.autograd.Function):
     """y = x @ W^T + b with autograd on (training): the forward and the input gradient run on the library's bf16x6
-    MFMA Linear kernel; the weight gradient dY^T @ X (a reduction over the whole batch) and the bias gradient are torch
-    reductions.  The nn.Linear module still owns the parameters (state_dict keys unchanged)."""
+    MFMA Linear kernel; the weight gradient dY^T @ X and the bias gradient (reductions over the whole batch) on
+    ``ocn_wgrad`` (split over the batch, partial sums added in a fixed order).  The nn.Linear module still owns the
+    parameters (state_dict keys unchanged)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -434,9 +435,10 @@ class _LinearFn(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = ops.linear_t(gy, weight) if ops.linear_ok_t(gy, weight) else gy @ weight
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            gw = gy.t() @ x
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gw, gb = ops.wgrad(gy, x, with_bias=want_b)
+        elif want_b:
             gb = gy.sum(0)
         return gx, gw, gb
 

@@ -29,6 +29,7 @@ walk_two_sided = True            # walk route: sweep each candidate from its che
 walk_share_min = 2               # walk route, B <= 4096: candidates sharing a source are swept together from this group size on (0 = never)
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 heavy_first = True               # ... and the pooling (H = 256) visits its slot groups longest first (ocn_cn_flags' gcost -> ocn_gather_schedule)
+deterministic_backward = os.environ.get("OCN_ATOMIC_BACKWARD", "0") != "1"   # pooling backward node by node in a fixed order (ocn_cn_gather_backward_det); else fp32 atomics
 
 
 def _on_device(fn):
@@ -504,7 +505,8 @@ def cn_gather3(rowptrA, colA, src, dst, off, flagsA, flagsB, wA: Tensor, wB: Ten
 @_on_device
 def cn_gather_backward(rowptrA, colA, src, dst, off, flags, wc, weights: Tensor, h: Tensor, g1: Tensor, g2: Tensor,
                        g3: Tensor, order: Optional[Tensor] = None) -> Tensor:
-    """Gradient of (xcn1, xcn2, xij) with respect to h."""
+    """Gradient of (xcn1, xcn2, xij) with respect to h: node by node in a fixed order (``deterministic_backward``, the
+    default), or with fp32 atomics (``OCN_ATOMIC_BACKWARD=1``)."""
     B, H = src.numel(), h.shape[1]
     for t, nm in ((g1, "g1"), (g2, "g2"), (g3, "g3")):
         if _req(t, torch.float32, nm, 2).shape != (B, H):
@@ -512,6 +514,14 @@ def cn_gather_backward(rowptrA, colA, src, dst, off, flags, wc, weights: Tensor,
     if H not in LN_WIDTHS:
         raise NotImplementedError(f"pooling backward supports hidden widths {LN_WIDTHS}, got {H}")
     dh = torch.zeros_like(h)
+    if deterministic_backward:
+        l = _lib.lib()
+        cap, N = flags.numel(), h.shape[0]
+        ws = torch.empty(int(l.ocn_cn_gather_backward_det_workspace_bytes(N, B, cap)), dtype=torch.uint8, device=h.device)
+        check(l.ocn_cn_gather_backward_det(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), B, ptr(off), ptr(flags), ptr(wc), cap,
+                                           ptr(weights), ptr(h), N, H, ptr(g1), ptr(g2), ptr(g3), ptr(dh), ptr(ws),
+                                           stream_ptr()), "ocn_cn_gather_backward_det")
+        return dh
     check(_lib.lib().ocn_cn_gather_backward(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off),
                                             ptr(flags), ptr(wc), ptr(weights), ptr(h), H, ptr(g1), ptr(g2), ptr(g3),
                                             ptr(dh), stream_ptr()), "ocn_cn_gather_backward")
@@ -821,6 +831,58 @@ def linear_t(gy: Tensor, weight: Tensor) -> Tensor:
     check(_lib.lib().ocn_linear_bf16x6(ptr(gy), M, N, ptr(panel), K, None, None, None, 0.0, 0, None, None, ptr(y),
                                        stream_ptr()), "ocn_linear_bf16x6")
     return y
+
+
+@_on_device
+def wgrad(gy: Tensor, x: Tensor, with_bias: bool = True):
+    """Weight / bias gradient of ``y = x @ W^T + b``: ``(gy^T @ x, gy.sum(0))`` — ``ocn_wgrad`` (bf16x6 on the matrix
+    cores, split over the batch, partial results added in slice order: deterministic).  gy [B, N], x [B, K] fp32 with
+    unit column stride (row strides free)."""
+    if gy.dim() == 2 and gy.stride(1) != 1:
+        gy = gy.contiguous()
+    if x.dim() == 2 and x.stride(1) != 1:
+        x = x.contiguous()
+    _req_strided(gy, "gy")
+    _req_strided(x, "x")
+    B, N = gy.shape
+    K = x.shape[1]
+    if x.shape[0] != B:
+        raise ValueError(f"wgrad: {tuple(gy.shape)} against {tuple(x.shape)}")
+    l = _lib.lib()
+    ws = torch.empty(int(l.ocn_wgrad_workspace_bytes(B, N, K)), dtype=torch.uint8, device=gy.device)
+    gw = torch.empty((N, K), dtype=torch.float32, device=gy.device)
+    gb = torch.empty((N,), dtype=torch.float32, device=gy.device) if with_bias else None
+    ldy = gy.stride(0) if B > 1 else max(N, gy.stride(0))
+    ldx = x.stride(0) if B > 1 else max(K, x.stride(0))
+    check(l.ocn_wgrad(ptr(gy), ldy, ptr(x), ldx, B, N, K, ptr(gw), ptr(gb) if with_bias else None, ptr(ws), stream_ptr()),
+          "ocn_wgrad")
+    return gw, gb
+
+
+@_on_device
+def coo_to_csr(row: Tensor, col: Tensor, n_rows: int, n_cols: int, symmetrize: bool = False, dedupe: bool = False,
+               check_range: bool = True):
+    """(rowptr int64[n_rows + 1], col int32[nnz']) of the pattern with entries (row[q], col[q]) — plus the transposed
+    entries when ``symmetrize`` — columns ascending per row, duplicates removed when ``dedupe`` (``ocn_coo_to_csr``:
+    counting pass, chained scan, fill, per-row sorts; no sort over the edge list).  ONE device -> host read (entries
+    written and the range status)."""
+    row = _req(row.contiguous(), torch.int64, "row", 1)
+    col = _req(col.contiguous(), torch.int64, "col", 1)
+    nnz = row.numel()
+    if col.numel() != nnz:
+        raise ValueError("coo_to_csr: row and col differ in length")
+    l = _lib.lib()
+    dev = row.device
+    ws = torch.empty(int(l.ocn_coo_to_csr_workspace_bytes(nnz, n_rows, int(symmetrize), int(dedupe))), dtype=torch.uint8, device=dev)
+    rowptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
+    out = torch.empty(nnz * (2 if symmetrize else 1), dtype=torch.int32, device=dev)
+    res = torch.empty(2, dtype=torch.int64, device=dev)
+    check(l.ocn_coo_to_csr(ptr(row), ptr(col), nnz, n_rows, n_cols, int(symmetrize), int(dedupe), ptr(rowptr), ptr(out),
+                           ptr(ws), ptr(res), stream_ptr()), "ocn_coo_to_csr")
+    n_out, bad = (int(v) for v in res.tolist())
+    if bad and check_range:
+        raise IndexError("SparseTensor: index out of range for sparse_sizes")
+    return rowptr, out[:n_out]
 
 
 def linear_grouped(groups, K: int, N: int) -> None:

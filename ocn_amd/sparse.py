@@ -66,6 +66,11 @@ class SparseTensor:
             n_cols = int(col.max()) + 1 if col.numel() else 0
             sparse_sizes = (n_rows, n_cols)
         self._sizes = (int(sparse_sizes[0]), int(sparse_sizes[1]))
+        if rowptr is None and value is None and not is_sorted and col.is_cuda:
+            # the per-batch adjacency of the training loop (NeighborOverlap_large.py:56-59): counting pass + per-row sorts
+            # on the device (ocn_coo_to_csr) instead of a comparison sort over the edge list
+            rowptr, col = ops.coo_to_csr(row.to(torch.int64), col.to(torch.int64), self._sizes[0], self._sizes[1],
+                                         check_range=not trust_data)
         if rowptr is None:
             row = row.to(torch.int64)
             col64 = col.to(torch.int64)
@@ -227,6 +232,10 @@ class SparseTensor:
     def to_symmetric(self, reduce: str = "sum") -> "SparseTensor":
         """Pattern of A ∪ Aᵀ, coalesced (values, if any, summed)."""
         r, c = self._row64(), self._col.to(torch.int64)
+        if self._value is None and self._col.is_cuda and self._sizes[0] == self._sizes[1]:
+            # NeighborOverlap_large.py:63: transposed entries join, duplicates leave — one pass of ocn_coo_to_csr
+            rowptr, col = ops.coo_to_csr(r, c, self._sizes[0], self._sizes[1], symmetrize=True, dedupe=True, check_range=False)
+            return SparseTensor(rowptr=rowptr, col=col, sparse_sizes=self._sizes)
         v = None if self._value is None else torch.cat([self._value, self._value])
         return SparseTensor(row=torch.cat([r, c]), col=torch.cat([c, r]), value=v,
                             sparse_sizes=self._sizes, trust_data=True).coalesce(reduce)

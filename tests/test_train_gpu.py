@@ -1,0 +1,171 @@
+"""GPU tests of the training-side kernels (NeighborOverlap_large.py:56-63, 76-90): the per-batch
+COO -> CSR build, the weight gradient and the deterministic pooling backward, through the C ABI."""
+import pytest
+import torch
+
+from ocn_amd import ops
+from ocn_amd.sparse import SparseTensor
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _ref_csr(row, col, n_rows, n_cols, symmetrize, dedupe):
+    """torch restatement on the CPU: sort by (row, col), optionally with the transposed entries and without duplicates."""
+    row, col = row.cpu(), col.cpu()
+    if symmetrize:
+        row, col = torch.cat([row, col]), torch.cat([col, row])
+    key = row * n_cols + col
+    key = torch.unique(key) if dedupe else torch.sort(key).values
+    r, c = torch.div(key, n_cols, rounding_mode="floor"), key % n_cols
+    rowptr = torch.zeros(n_rows + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=n_rows), 0)
+    return rowptr, c.to(torch.int32)
+
+
+def _coo_case(name):
+    g = torch.Generator().manual_seed(7)
+    if name == "small":                      # rows of every short length, duplicates, empty rows
+        n = 300
+        row = torch.randint(0, n - 20, (4000,), generator=g)
+        col = torch.randint(0, n, (4000,), generator=g)
+    elif name == "hubs":                     # rows longer than a wave, longer than the LDS sort (12 288), one of 40 000
+        n = 60000
+        parts_r = [torch.randint(0, n, (200000,), generator=g), torch.full((40000,), 5), torch.full((9000,), 77),
+                   torch.full((300,), 11)]
+        parts_c = [torch.randint(0, n, (200000,), generator=g), torch.randint(0, n, (40000,), generator=g),
+                   torch.randint(0, 3000, (9000,), generator=g), torch.randint(0, 200, (300,), generator=g)]
+        row, col = torch.cat(parts_r), torch.cat(parts_c)
+    elif name == "collab":                   # the size the training loop builds per batch
+        n = 235868
+        row = torch.randint(0, n, (1_100_000,), generator=g)
+        col = torch.randint(0, n, (1_100_000,), generator=g)
+    else:
+        raise KeyError(name)
+    return n, row, col
+
+
+@pytest.mark.parametrize("name", ["small", "hubs", "collab"])
+@pytest.mark.parametrize("symmetrize,dedupe", [(False, False), (True, True), (False, True)])
+def test_coo_to_csr_equals_sort_and_unique(hiplib, name, symmetrize, dedupe):
+    n, row, col = _coo_case(name)
+    rowptr, out = ops.coo_to_csr(row.to(DEV), col.to(DEV), n, n, symmetrize=symmetrize, dedupe=dedupe)
+    rp, c = _ref_csr(row, col, n, n, symmetrize, dedupe)
+    assert torch.equal(rowptr.cpu(), rp)
+    assert out.dtype == torch.int32 and torch.equal(out.cpu(), c)
+
+
+def test_coo_to_csr_edge_cases(hiplib):
+    e = torch.empty(0, dtype=torch.int64, device=DEV)
+    rowptr, out = ops.coo_to_csr(e, e, 5, 5, symmetrize=True, dedupe=True)
+    assert rowptr.tolist() == [0] * 6 and out.numel() == 0
+    rowptr, out = ops.coo_to_csr(e, e, 0, 0)
+    assert rowptr.tolist() == [0] and out.numel() == 0
+    # rectangular, no symmetrisation; a self loop is its own transpose
+    r = torch.tensor([2, 0, 2, 2], device=DEV)
+    c = torch.tensor([6, 1, 0, 6], device=DEV)
+    rowptr, out = ops.coo_to_csr(r, c, 3, 7, dedupe=True)
+    assert rowptr.tolist() == [0, 1, 1, 3] and out.tolist() == [1, 0, 6]
+    rowptr, out = ops.coo_to_csr(torch.tensor([1, 1], device=DEV), torch.tensor([1, 0], device=DEV), 2, 2, symmetrize=True, dedupe=True)
+    assert rowptr.tolist() == [0, 1, 3] and out.tolist() == [1, 0, 1]
+    with pytest.raises(IndexError):
+        ops.coo_to_csr(torch.tensor([0, 3], device=DEV), torch.tensor([1, 1], device=DEV), 3, 3)
+    with pytest.raises(IndexError):
+        ops.coo_to_csr(torch.tensor([0, 1], device=DEV), torch.tensor([1, -1], device=DEV), 3, 3)
+
+
+def test_sparse_tensor_builds_the_masked_adjacency_on_the_library(hiplib, monkeypatch):
+    """The drivers' per-batch build (NeighborOverlap_large.py:56-63) through the product's SparseTensor: the same CSR as
+    the torch restatement, built by ocn_coo_to_csr (twice: from_edge_index, to_symmetric) with torch's sort / unique never
+    called.  (The kernel list of a training step is profiles/r03_train_step_kernel_stats.csv.)"""
+    n, row, col = _coo_case("collab")
+    tei = torch.stack([row, col]).to(DEV)
+    calls = []
+    real = ops.coo_to_csr
+    monkeypatch.setattr(ops, "coo_to_csr", lambda *a, **k: (calls.append(k), real(*a, **k))[1])
+    for name in ("sort", "argsort", "unique", "unique_consecutive"):
+        monkeypatch.setattr(torch, name, lambda *a, _n=name, **k: (_ for _ in ()).throw(AssertionError(f"torch.{_n} called")))
+    adj = SparseTensor.from_edge_index(tei, sparse_sizes=(n, n)).to_device(DEV, non_blocking=True)
+    adj = adj.to_symmetric()
+    monkeypatch.undo()
+    assert len(calls) == 2 and calls[1].get("symmetrize") and calls[1].get("dedupe")
+    rp, c = _ref_csr(row, col, n, n, True, True)
+    rowptr, colx, _ = adj.csr()
+    assert torch.equal(rowptr.cpu(), rp) and torch.equal(colx.cpu().to(torch.int32), c)
+
+
+WGRAD_SHAPES = [(65536, 256, 256), (1000, 256, 256), (4096, 64, 64), (2048, 32, 32), (77, 1, 33), (1152, 256, 1433),
+                (5000, 200, 58), (16, 128, 128), (3, 5, 7)]
+
+
+@pytest.mark.parametrize("B,N,K", WGRAD_SHAPES, ids=lambda v: str(v))
+def test_wgrad_is_as_accurate_as_an_fp32_gemm_and_deterministic(hiplib, B, N, K):
+    """dW = dY^T X and db = column sums against an fp64 evaluation: error no worse than twice torch's own fp32 GEMM (floor
+    1e-6 of the largest entry); two runs give the same bits (partial sums are added in a fixed order)."""
+    g = torch.Generator().manual_seed(B + N + K)
+    gy = (torch.randn(B, N, generator=g) * torch.logspace(-3, 2, N)).to(DEV)        # columns of mixed magnitude
+    x = (torch.randn(B, K, generator=g) * (1.0 + 5.0 * torch.rand(B, 1, generator=g))).to(DEV)
+    gw, gb = ops.wgrad(gy, x)
+    gw2, gb2 = ops.wgrad(gy, x)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    ref = gy.double().t() @ x.double()
+    ref_b = gy.double().sum(0)
+    err = (gw.double() - ref).abs().max().item()
+    err_t = ((gy.t() @ x).double() - ref).abs().max().item()
+    assert err <= 2 * err_t + 1e-6 * ref.abs().max().item(), (err, err_t)
+    err_b = (gb.double() - ref_b).abs().max().item()
+    assert err_b <= 2 * (gy.sum(0).double() - ref_b).abs().max().item() + 1e-6 * ref_b.abs().max().item()
+    gw3, none = ops.wgrad(gy, x, with_bias=False)
+    assert none is None and torch.equal(gw3, gw)
+
+
+def test_wgrad_reads_strided_rows(hiplib):
+    """A layer's input / upstream gradient may be one half of a wider buffer (row stride > width)."""
+    g = torch.Generator().manual_seed(3)
+    wide_y = torch.randn(3000, 96, generator=g).to(DEV)
+    wide_x = torch.randn(3000, 200, generator=g).to(DEV)
+    gy, x = wide_y[:, 32:96], wide_x[:, :128]
+    gw, gb = ops.wgrad(gy, x)
+    gwc, gbc = ops.wgrad(gy.contiguous(), x.contiguous())
+    assert torch.equal(gw, gwc) and torch.equal(gb, gbc)
+    gw0, gb0 = ops.wgrad(torch.empty(0, 8, device=DEV), torch.empty(0, 4, device=DEV))
+    assert gw0.shape == (8, 4) and not gw0.any() and not gb0.any()
+
+
+def _pool_case(n, avg, mx, B, H, seed, walk=False):
+    from oracle import ocn_oracle as O   # graph generator helpers only
+    from tests.helpers import batch, make_graph, product_adj2, to_product
+    from ocn_amd.utils import adjoverlap
+    oadj = make_graph(n, avg, mx, seed)
+    e = batch(oadj, B, seed + 5).to(DEV)
+    adj = to_product(oadj, DEV)
+    return adj, product_adj2(adj), e
+
+
+@pytest.mark.parametrize("n,avg,mx,B,H", [(500, 8, 100, 300, 32), (3000, 12, 400, 2048, 64), (20000, 10, 600, 8192, 256),
+                                          (2000, 30, 1500, 4096, 128)], ids=lambda v: str(v))
+@pytest.mark.parametrize("name", ["cn5", "cn7"])
+def test_pooling_backward_is_deterministic_and_equals_the_atomic_form(hiplib, monkeypatch, name, n, avg, mx, B, H):
+    """The node-by-node pooling backward (ocn_cn_gather_backward_det): the same bits on every run, and the atomic kernel's
+    result to rounding (fp32 sums in another order)."""
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    from types import SimpleNamespace
+    adj, adj2, e = _pool_case(n, avg, mx, B, H, seed=n + B)
+    torch.manual_seed(1)
+    pred = predictor_dict[name](H, H, 1, 3, 0.0, 0.0, True).eval().to(DEV)
+    x = torch.randn(n, H, device=DEV)
+    wgt = torch.randn(B, 1, device=DEV)
+
+    def grad():
+        xd = x.clone().requires_grad_(True)
+        out = pred(xd, adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e), e, SimpleNamespace(sum=1.0))
+        (out * wgt).sum().backward()
+        return xd.grad
+
+    monkeypatch.setattr(ops, "deterministic_backward", True)
+    a, b = grad(), grad()
+    assert torch.equal(a, b)
+    monkeypatch.setattr(ops, "deterministic_backward", False)
+    c = grad()
+    assert (a - c).abs().max().item() <= 2e-5 * max(1.0, c.abs().max().item())
