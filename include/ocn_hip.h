@@ -240,14 +240,21 @@ int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64
  * out_row[e] of the three outputs (ocn_class_order's inv_out: class-major rows for the heads).
  * cnt1 / cnt2 (or NULL): the per-row CN counts of the intersection pass; a row with neither kind of
  * entry is not walked at all, and with out_row the xcn1 / xcn2 rows the class-major heads never read
- * (no cn1 entry; no entry at all) are not written. */
+ * (no cn1 entry; no entry at all) are not written.
+ * rowsum (or NULL; pattern route with the cn7 weights only — the caller's promise that every cn2 entry has weight
+ * exactly 1 and no cn1 correction): [N][H] rows (A h)[i] = sum_{k in N(i)} h[k] in ascending column order
+ * (ocn_spmm_csr, mode sum).  A candidate whose WHOLE source row is cn2 (cnt2[e] = row length: the target's A^2 row
+ * holds every neighbour of the source — ogbl-ddi, whose A^2 is full) has xcn2[e] = rowsum[src[e]], the same additions in
+ * the same order, so the row is copied instead of summed again for every candidate of that source; only its cn1 entries
+ * are gathered. */
 int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA,
                   const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                   const int64_t* off, const uint8_t* flags, const int32_t* wc,
                   const float* weights /* [N][4] */, const float* h, int32_t H, int64_t max_row_len,
                   float* xcn1, float* xcn2, float* xij, const int64_t* out_row,
                   const int32_t* cnt1, const int32_t* cnt2, const uint64_t* rec /* or NULL */,
-                  const int32_t* perm /* ocn_gather_schedule's, or NULL */, void* stream);
+                  const int32_t* perm /* ocn_gather_schedule's, or NULL */, const float* rowsum /* or NULL */,
+                  void* stream);
 /* The pooling's visiting order at H = 256 (a workgroup = four candidates = one group of ocn_cn_flags' gcost): candidates
  * differ 100x in cost and the few with hundreds of rows, met late, end the kernel as stragglers (0.206 -> 0.17 ms at the
  * collab shape).  perm[] = inside each XCD's contiguous eighth of the groups, the groups stable-sorted by descending cost:

@@ -41,6 +41,7 @@ __device__ __forceinline__ bool sampled_has(const int32_t* samp, const int32_t* 
 // ---------------------------------------------------------------------------------------------
 #define T1_CAP 1024
 #define REC_LEN_SHIFT 40                     /* slot record word 2: row start (nnz < 2^40) | row length << 40 */
+#define REC_FULL2_BIT 61     /* record word 3: every position of the source row is a cn2 entry (cnt2 == row length) */
 #ifndef OCN_X_G
 #define OCN_X_G 64     /* lanes per candidate edge; tools/kbench.py overrides it for timing experiments */
 #endif
@@ -144,6 +145,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
         const u64 inc = (u64)f1 | ((u64)f2 << HF_BITS) | (1ull << (2 * HF_BITS));
 #ifdef OCN_X_ATOMIC_SPREAD   /* timing experiment: the same number of atomics on uniformly spread addresses (no hot column) */
         if (LH) atomicAdd(s_hist + k, inc); else atomicAdd(hist + 2 * (i64)((((u64)k * 2654435761ull) ^ ((u64)(base + p) * 40503ull)) % (u64)n_cols), inc);
+#elif defined(OCN_X_ATOMIC_WG)  /* timing experiment: the atomics resolved in the issuing XCD's L2 (results wrong across XCDs) */
+        if (LH) atomicAdd(s_hist + k, inc); else __hip_atomic_fetch_add(hist + 2 * (i64)k, inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
         if (LH) atomicAdd(s_hist + k, inc); else atomicAdd(hist + 2 * (i64)k, inc);
 #endif
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
         r[0] = (u64)e;
         r[1] = (u64)i | ((u64)j << 32);
         r[2] = (u64)a0 | ((u64)da << REC_LEN_SHIFT);
-        r[3] = (u64)base | ((u64)(c1 > 0) << 62) | ((u64)(c2 > 0) << 63);
+        r[3] = (u64)base | ((u64)(da > 0 && (i64)c2 == da) << REC_FULL2_BIT) | ((u64)(c1 > 0) << 62) | ((u64)(c2 > 0) << 63);
       }
     }
     if (gcost) {
@@ -641,7 +644,7 @@ __device__ __forceinline__ void pool_range(i64 p_begin, i64 p_end, i64 a0, i64 b
                                            const int32_t* __restrict__ colA, const uint8_t* __restrict__ flags,
                                            const int32_t* __restrict__ wc, const float4* __restrict__ weights,
                                            const float4* __restrict__ h4, i64 rowq, float4 (&acc1)[NV],
-                                           float4 (&acc2)[NV]) {
+                                           float4 (&acc2)[NV], bool full2 = false) {
   // Narrow groups (small H) would otherwise pay one dependent load chain (column id -> column weights)
   // per LPE positions: a lane fetches PT positions per round, so a round always covers 64 of them
   // (hub rows of the ppa shape: 101 -> 40 us).
@@ -664,6 +667,7 @@ __device__ __forceinline__ void pool_range(i64 p_begin, i64 p_end, i64 a0, i64 b
         k[t] = colA[a0 + p]; f[t] = flags[base + p];
         if (wc) cv[t] = wc[base + p];
       }
+      if (full2) f[t] &= ~OCN_F_CN2;           // the whole row is cn2: its pooled vector is the row sum (rowsum), not summed here
     }
     float wa[PT], wb[PT];
 #pragma unroll
@@ -765,7 +769,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
     const i64* __restrict__ out_row,     // out_row[batch row] = output row (class-major heads), or NULL
     const int32_t* __restrict__ cnt1, const int32_t* __restrict__ cnt2,     // per-row CN counts, or NULL
     const u64* __restrict__ rec,         // slot records of the intersection pass (then order/src/dst/off/cnt are not read), or NULL
-    const int32_t* __restrict__ perm) {  // ocn_gather_schedule's visiting order of the slot groups (longest first per XCD), or NULL
+    const int32_t* __restrict__ perm,    // ocn_gather_schedule's visiting order of the slot groups (longest first per XCD), or NULL
+    const float* __restrict__ rowsum) {  // (A h)[i] rows for candidates whose whole source row is cn2 with weight 1 (ocn_hip.h), or NULL
   constexpr int GPW = OCN_WAVE / LPE;
   const int lane = threadIdx.x & 63;
   const int gl = lane % LPE;
@@ -793,13 +798,14 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
   // One dependent load instead of three (order -> src / dst / off / counts -> rowptr) in front of the first gather:
   // the intersection pass left everything about this slot in a 32-byte record.
   i64 e, i, j, a0, da, base;
-  bool has1, has2;
+  bool has1, has2, full2;
   if (rec) {
     const ulonglong2* rp = reinterpret_cast<const ulonglong2*>(rec + 4 * slot);
     const ulonglong2 ra = rp[0], rb = rp[1];
     e = (i64)ra.x; i = (i64)(ra.y & 0xffffffffull); j = (i64)(ra.y >> 32);
     a0 = (i64)(rb.x & ((1ull << REC_LEN_SHIFT) - 1)); da = (i64)(rb.x >> REC_LEN_SHIFT);
-    base = (i64)(rb.y & ((1ull << 62) - 1)); has1 = (rb.y >> 62) & 1ull; has2 = rb.y >> 63;
+    base = (i64)(rb.y & ((1ull << REC_FULL2_BIT) - 1)); has1 = (rb.y >> 62) & 1ull; has2 = rb.y >> 63;
+    full2 = rowsum && ((rb.y >> REC_FULL2_BIT) & 1ull);
   } else {
     e = order ? order[slot] : slot;
     i = src[e]; j = dst[e];
@@ -808,15 +814,21 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
     // a candidate without any CN entry (half of an evaluation batch) has nothing to pool; with class-major
     // output rows the heads never read its xcn1 / xcn2 rows (nor the xcn1 row of one without cn1 entries)
     has1 = !cnt1 || cnt1[e] > 0; has2 = !cnt2 || cnt2[e] > 0;
+    full2 = rowsum && cnt2 && da > 0 && (i64)cnt2[e] == da;
   }
-  if (da > LONG_ROW) return;                // cn_gather_long_kernel's
+  if (da > LONG_ROW && !full2) return;      // cn_gather_long_kernel's (a hub row whose cn2 is the whole row only has its cn1 entries left)
   const float4* h4 = reinterpret_cast<const float4*>(h) + slice * (LPE * NV);
   const i64 rowq = H >> 2;                  // float4 per row
   if (SLICED) { xcn1 += slice * (LPE * NV * 4); xcn2 += slice * (LPE * NV * 4); xij += slice * (LPE * NV * 4); }
   float4 acc1[NV], acc2[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc1[v] = acc2[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (has1 | has2) pool_range<LPE, NV>(0, da, a0, base, gl, gbase, colA, flags, wc, weights, h4, rowq, acc1, acc2);
+  if (has1 | (has2 & !full2)) pool_range<LPE, NV>(0, da, a0, base, gl, gbase, colA, flags, wc, weights, h4, rowq, acc1, acc2, full2);
+  if (full2) {
+    const float4* rs = reinterpret_cast<const float4*>(rowsum) + slice * (LPE * NV) + i * rowq + gl;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc2[v] = rs[v * LPE];
+  }
   pool_store<LPE, NV>(out_row ? out_row[e] : e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij,
                       !out_row || has1, !out_row || has1 || has2);
 }
@@ -884,7 +896,8 @@ __global__ __launch_bounds__(WPB * OCN_WAVE) void cn_gather_wave_kernel(
     const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
     float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij,
-    const i64* __restrict__ out_row) {   // out_row[batch row] = output row (class-major heads), or NULL
+    const i64* __restrict__ out_row,     // out_row[batch row] = output row (class-major heads), or NULL
+    const int32_t* __restrict__ cnt2, const float* __restrict__ rowsum) {   // see cn_gather_kernel
   // WPB waves per workgroup: ONE for the LONG pass — most batch rows are not its and leave at once, and a wave that
   // has left frees its LDS slab only when it is a workgroup of its own.
   constexpr int G = OCN_WAVE / LPE;
@@ -901,7 +914,8 @@ __global__ __launch_bounds__(WPB * OCN_WAVE) void cn_gather_wave_kernel(
   const i64 e = order ? order[slot] : slot;
   const i64 i = src[e], j = dst[e];
   const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
-  if (LONG ? da <= LONG_ROW : da > LONG_ROW) return;       // the other launch's rows
+  const bool full2 = rowsum && cnt2 && da > 0 && (i64)cnt2[e] == da;
+  if (LONG ? (da <= LONG_ROW || full2) : (da > LONG_ROW && !full2)) return;       // the other launch's rows
   const i64 base = off[e];
   const float4* h4 = reinterpret_cast<const float4*>(h);
   const i64 rowq = H >> 2;
@@ -911,9 +925,10 @@ __global__ __launch_bounds__(WPB * OCN_WAVE) void cn_gather_wave_kernel(
   // round r's rows are; round r+1 is compacted and its rows requested (into registers) before round r is summed.
   int32_t k_n = 0, k_nn = 0, cv_n = 1, cv_nn = 1;
   unsigned f_n = 0, f_nn = 0;
-  if (lane < da) { k_n = colA[a0 + lane]; f_n = flags[base + lane]; if (wc) cv_n = wc[base + lane]; }
+  const unsigned fmask = full2 ? ~OCN_F_CN2 : ~0u;          // (full2: the row's cn2 pool is rowsum[i])
+  if (lane < da) { k_n = colA[a0 + lane]; f_n = flags[base + lane] & fmask; if (wc) cv_n = wc[base + lane]; }
   if (OCN_WAVE + lane < da) {
-    k_nn = colA[a0 + OCN_WAVE + lane]; f_nn = flags[base + OCN_WAVE + lane];
+    k_nn = colA[a0 + OCN_WAVE + lane]; f_nn = flags[base + OCN_WAVE + lane] & fmask;
     if (wc) cv_nn = wc[base + OCN_WAVE + lane];
   }
   float4 w_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -930,7 +945,7 @@ __global__ __launch_bounds__(WPB * OCN_WAVE) void cn_gather_wave_kernel(
     if (f_n) w_n = weights[k_n];
     k_nn = 0; f_nn = 0; cv_nn = 1;
     if (p0 + 2 * OCN_WAVE + lane < da) {
-      k_nn = colA[a0 + p0 + 2 * OCN_WAVE + lane]; f_nn = flags[base + p0 + 2 * OCN_WAVE + lane];
+      k_nn = colA[a0 + p0 + 2 * OCN_WAVE + lane]; f_nn = flags[base + p0 + 2 * OCN_WAVE + lane] & fmask;
       if (wc) cv_nn = wc[base + p0 + 2 * OCN_WAVE + lane];
     }
     float wa = 0.f, wb = 0.f;
@@ -975,7 +990,7 @@ __global__ __launch_bounds__(WPB * OCN_WAVE) void cn_gather_wave_kernel(
   if (lane < HF) {
     const i64 o = (out_row ? out_row[e] : e) * H + lane;
     xcn1[o] = acc1[0];
-    xcn2[o] = acc2[0];
+    xcn2[o] = full2 ? rowsum[i * H + lane] : acc2[0];
     xij[o] = __fmul_rn(h[i * H + lane], h[j * H + lane]);
   }
 }
@@ -1033,7 +1048,8 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
     const i64* __restrict__ off, const uint8_t* __restrict__ flags, const int32_t* __restrict__ wc,
     const float4* __restrict__ weights, const float* __restrict__ h, int H,
     float* __restrict__ xcn1, float* __restrict__ xcn2, float* __restrict__ xij,
-    const i64* __restrict__ out_row) {   // out_row[batch row] = output row (class-major heads), or NULL
+    const i64* __restrict__ out_row,     // out_row[batch row] = output row (class-major heads), or NULL
+    const int32_t* __restrict__ cnt2, const float* __restrict__ rowsum) {   // see cn_gather_kernel
   constexpr int FG = (LONG_THREADS - OCN_WAVE) / LPE;          // fetching lane groups (waves 1..)
   constexpr int ROWQ = LPE * NV;                               // float4 per embedding row
   constexpr int HF = ROWQ * 4;                                 // features
@@ -1051,6 +1067,7 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
   const i64 i = src[e], j = dst[e];
   const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
   if (da <= LONG_ROW) return;               // whole workgroup leaves together
+  if (rowsum && cnt2 && (i64)cnt2[e] == da) return;            // ... also for a row pooled from rowsum by the other launch
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int gl = threadIdx.x % LPE, fg = ((int)threadIdx.x - OCN_WAVE) / LPE;
   const i64 base = off[e];
@@ -1339,7 +1356,7 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
                           const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
                           const int32_t* wc, const float* weights, const float* h, int32_t H, int64_t max_row_len,
                           float* xcn1, float* xcn2, float* xij, const int64_t* out_row, const int32_t* cnt1,
-                          const int32_t* cnt2, const uint64_t* rec, const int32_t* perm, hipStream_t st) {
+                          const int32_t* cnt2, const uint64_t* rec, const int32_t* perm, const float* rowsum, hipStream_t st) {
   const i64 epb = (i64)OCN_WPB * (OCN_WAVE / LPE);
   // the schedule's groups are the workgroups of the intersection pass: usable where the pooling's workgroups are the same
   const bool sched = perm && rec && epb == SCHED_GROUP && ((B + epb - 1) / epb) % 8 == 0;
@@ -1349,7 +1366,7 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
       hipLaunchKernelGGL((cn_gather_wave_kernel<LPE, NV>), dim3((unsigned)((B + OCN_WPB - 1) / OCN_WPB)),
                          dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst,
                          (const i64*)order, (i64)B, (const i64*)off, flags, wc, (const float4*)weights, h, (int)H,
-                         xcn1, xcn2, xij, (const i64*)out_row);
+                         xcn1, xcn2, xij, (const i64*)out_row, cnt2, rowsum);
       packed = false;
     }
   }
@@ -1366,18 +1383,18 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
       const i64 spb = (i64)OCN_WPB * (OCN_WAVE / SL);
       if (B >= GATHER_SLICE_MIN_BATCH) {
         hipLaunchKernelGGL((cn_gather_kernel<SL, 1, true>), dim3((unsigned)(8 * ((B + spb - 1) / spb))), dim3(OCN_BLOCK),
-                           0, st, PACKED_ARGS, (const int32_t*)nullptr);
+                           0, st, PACKED_ARGS, (const int32_t*)nullptr, rowsum);
         sliced = true;
       }
     }
 #endif
     if (!sliced)
       hipLaunchKernelGGL((cn_gather_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)), dim3(OCN_BLOCK), 0, st,
-                         PACKED_ARGS, sched ? perm : (const int32_t*)nullptr);
+                         PACKED_ARGS, sched ? perm : (const int32_t*)nullptr, rowsum);
   }
 #undef PACKED_ARGS
 #define LONG_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, wc, \
-                  (const float4*)weights, h, (int)H, xcn1, xcn2, xij, (const i64*)out_row
+                  (const float4*)weights, h, (int)H, xcn1, xcn2, xij, (const i64*)out_row, cnt2, rowsum
   if (max_row_len > LONG_ROW) {
     if (B <= 4096) {
       static bool raised_dev[64] = {};        // 2 x 64 KiB of slab: above the default dynamic-LDS limit (attribute is per device)
@@ -1393,7 +1410,7 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
       if constexpr (LPE <= 16) {             // narrow embeddings: a wave per hub row, 64 gathers in flight each
         hipLaunchKernelGGL((cn_gather_wave_kernel<LPE, NV, true>), dim3((unsigned)B), dim3(OCN_WAVE), 0, st, (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst,
                            (const i64*)order, (i64)B, (const i64*)off, flags, wc, (const float4*)weights, h, (int)H,
-                           xcn1, xcn2, xij, (const i64*)out_row);
+                           xcn1, xcn2, xij, (const i64*)out_row, cnt2, rowsum);
         by_wave = true;
       }
       if (!by_wave) hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV, 256>), dim3((unsigned)B), dim3(256), 2 * LONG_SLAB_BYTES(256), st, LONG_ARGS);
@@ -1538,7 +1555,7 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream) 
 #define GATHER_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (const i64*)order, (i64)B, (const i64*)off, \
                     flags, wc, (const float4*)weights, h, (int)H, xcn1, xcn2, xij, (const i64*)out_row
 #define LAUNCH_GATHER(LPE, NV)                                                                      \
-  launch_gather<LPE, NV>(rowptrA, colA, src, dst, order, B, off, flags, wc, weights, h, H, max_row_len, xcn1, xcn2, xij, out_row, cnt1, cnt2, rec, perm, st)
+  launch_gather<LPE, NV>(rowptrA, colA, src, dst, order, B, off, flags, wc, weights, h, H, max_row_len, xcn1, xcn2, xij, out_row, cnt1, cnt2, rec, perm, rowsum, st)
 
 // The visiting order of the pooling's slot groups: each XCD's contiguous eighth of the groups, stable-sorted by
 // descending cost (64 buckets) — one workgroup per eighth, a counting sort in LDS: thread t counts the
@@ -1594,10 +1611,12 @@ int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* sr
                   const int64_t* dst, const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flags,
                   const int32_t* wc, const float* weights, const float* h, int32_t H,
                   int64_t max_row_len, float* xcn1, float* xcn2, float* xij, const int64_t* out_row,
-                  const int32_t* cnt1, const int32_t* cnt2, const uint64_t* rec, const int32_t* perm, void* stream) {
+                  const int32_t* cnt1, const int32_t* cnt2, const uint64_t* rec, const int32_t* perm, const float* rowsum,
+                  void* stream) {
   if (B < 0 || H <= 0) return OCN_EINVAL;
   if (B == 0) return 0;
   if (!rowptrA || !src || !dst || !off || !weights || !h || !xcn1 || !xcn2 || !xij) return OCN_EINVAL;
+  if (rowsum && (wc || !cnt2)) return OCN_EINVAL;          // the shortcut is the pattern route's, and needs the per-row counts
   hipStream_t st = (hipStream_t)stream;
   switch (H) {
     case 16:  LAUNCH_GATHER(4, 1); break;

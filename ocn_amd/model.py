@@ -569,11 +569,16 @@ class _CNPredictorBase(nn.Module):
             return _PoolFn.apply(x, st, w)
         if not getattr(st, "_cls_decided", False):
             self._class_order(st, x)
+        rs = self._rowsum(st, x)
         if st.cls is not None:
             # (the pooling keeps its own source-sorted, XCD-balanced processing order and only WRITES to the
             # class-major rows: processed class-major, the XCDs holding the heavy classes ran 50 % longer)
-            return st.gather(w, x, out_row=st.cls[1])
-        return st.gather(w, x)
+            return st.gather(w, x, out_row=st.cls[1], rowsum=rs)
+        return st.gather(w, x, rowsum=rs)
+
+    def _rowsum(self, st, x):
+        """None here: cn5's cn2 weights depend on the batch and on the entry's cn1 flag.  cn7 overrides."""
+        return None
 
     # Whether skipping pays is a property of the data (a dense graph such as ddi has common neighbours for
     # every candidate: the re-ordering then only costs).  The class boundaries of a batch are copied to pinned
@@ -927,6 +932,24 @@ class CNLinkPredictorbaselearn(_CNPredictorBase):
 
     def _weights(self, st, args):
         return st.weights_cn7(float(args.sum))
+
+    def _rowsum(self, st, x):
+        """A·h, once per (embeddings, adjacency): cn7's cn2 weights are exactly 1 (raw cn2, model.py:3186-3209), so a
+        candidate whose target's A² row holds EVERY neighbour of its source — the rule on a dense graph, ogbl-ddi's A² is
+        full — has xcn2 = (A·h)[source], the same additions in the same order; the pooling copies that row instead of
+        summing ~500 embedding rows again for each of the source's candidates (ocn_hip.h, ocn_cn_gather `rowsum`).  Only
+        where it can pay: pattern route, A² at least half full."""
+        adj, t2 = st.adj, getattr(st, "t2", None)
+        if not ops.share_full_rows or st.walk or t2 is None or not x.is_cuda or x.dim() != 2:
+            return None
+        n = adj.size(0)
+        if t2.nnz() * 2 < n * n or adj.size(1) != x.shape[0] or n != x.shape[0]:
+            return None
+        key = (x.data_ptr(), x._version, tuple(x.shape), id(adj))
+        hit = getattr(self, "_rowsum_cache", None)
+        if hit is None or hit[0] != key:
+            hit = self._rowsum_cache = (key, ops.spmm_csr(adj._rowptr, adj._col, x), adj)      # (adj kept: its id stays its own)
+        return hit[1]
 
     def forward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False):
         # the drivers pass the argparse Namespace in this slot (NeighborOverlap_large.py:122)

@@ -29,6 +29,7 @@ walk_two_sided = True            # walk route: sweep each candidate from its che
 walk_share_min = 2               # walk route, B <= 4096: candidates sharing a source are swept together from this group size on (0 = never)
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 heavy_first = True               # ... and the pooling (H = 256) visits its slot groups longest first (ocn_cn_flags' gcost -> ocn_gather_schedule)
+share_full_rows = True           # cn7 on a dense graph: candidates whose whole source row is cn2 copy (A h)[source] (ocn_cn_gather `rowsum`)
 deterministic_backward = os.environ.get("OCN_ATOMIC_BACKWARD", "0") != "1"   # pooling backward node by node in a fixed order (ocn_cn_gather_backward_det); else fp32 atomics
 
 
@@ -417,13 +418,15 @@ def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
 def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights: Tensor, h: Tensor,
               order: Optional[Tensor] = None, max_row_len: int = 0, wsd=None, out_row: Optional[Tensor] = None,
               cnt1: Optional[Tensor] = None, cnt2: Optional[Tensor] = None, rec: Optional[Tensor] = None,
-              sched: Optional[Tensor] = None):
+              sched: Optional[Tensor] = None, rowsum: Optional[Tensor] = None):
     _req(weights, torch.float32, "weights", 2)
     _req(h, torch.float32, "h", 2)
     if weights.shape[0] != h.shape[0] or weights.shape[1] != 4:
         raise ValueError("weights must be [N,4] with N = h.shape[0]")
     B, H = src.numel(), h.shape[1]
     out = buf(wsd, "pooled", (3, B, H), torch.float32, h.device)
+    if rowsum is not None and (wc is not None or cnt2 is None or _req(rowsum, torch.float32, "rowsum", 2).shape != h.shape):
+        raise ValueError("rowsum: [N, H] row sums of h, pattern route with per-row counts only")
     perm = None
     if sched is not None and rec is not None and H == 256 and B % 32 == 0 and B // 32 <= 65535:
         n_groups = B // 4             # the intersection pass left the groups' costs in sched[:n_groups]; their visiting order follows
@@ -431,7 +434,7 @@ def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights
         check(_lib.lib().ocn_gather_schedule(ptr(sched), n_groups, ptr(perm), stream_ptr()), "ocn_gather_schedule")
     check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags),
                                    ptr(wc), ptr(weights), ptr(h), H, int(max_row_len), ptr(out[0]), ptr(out[1]),
-                                   ptr(out[2]), ptr(out_row), ptr(cnt1), ptr(cnt2), ptr(rec), ptr(perm),
+                                   ptr(out[2]), ptr(out_row), ptr(cnt1), ptr(cnt2), ptr(rec), ptr(perm), ptr(rowsum),
                                    stream_ptr()), "ocn_cn_gather")
     _mark("cn_gather")
     return out[0], out[1], out[2]

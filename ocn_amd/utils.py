@@ -57,7 +57,7 @@ class CNState:
                 raise ValueError("adjoverlap: adjacency sizes differ")    # utils.py:164 assert
         if walk and adj.size(0) != adj.size(1):
             raise ValueError("get_cn1_cn2 needs a square adjacency")
-        self.adj, self.walk = adj, walk
+        self.adj, self.walk, self.t2 = adj, walk, t2
         self.ws = ws                           # a predictor's scratch cache: this state is then transient
         self.src = tarei[0].to(torch.int64).contiguous()
         self.dst = tarei[1].to(torch.int64).contiguous()
@@ -159,14 +159,17 @@ class CNState:
         self._hist_live = False
         return ops.cn_weights_cn7(self.hist, sum_fill)
 
-    def gather(self, weights: Tensor, h: Tensor, order: Optional[Tensor] = None, out_row: Optional[Tensor] = None):
+    def gather(self, weights: Tensor, h: Tensor, order: Optional[Tensor] = None, out_row: Optional[Tensor] = None,
+               rowsum: Optional[Tensor] = None):
         """(xcn1, xcn2, x_i * x_j); ``order`` overrides the processing order, ``out_row`` sends batch row e
-        to output row out_row[e] (class-major rows for the heads, ops.class_order)."""
+        to output row out_row[e] (class-major rows for the heads, ops.class_order); ``rowsum`` = A·h for the cn7 weights
+        (ocn_hip.h, ocn_cn_gather: candidates whose whole source row is cn2 copy their xcn2 row)."""
         return ops.cn_gather(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off,
                              self.flags, self.wc, weights, h, order=self.order if order is None else order,
                              max_row_len=self.adj.max_rowcount(), wsd=self.ws, out_row=out_row,
                              cnt1=self.cnt1, cnt2=self.cnt2, rec=getattr(self, "rec", None) if order is None else None,
-                             sched=getattr(self, "sched", None) if order is None else None)
+                             sched=getattr(self, "sched", None) if order is None else None,
+                             rowsum=None if self.walk else rowsum)
 
     def gather_backward(self, weights: Tensor, h: Tensor, g1: Tensor, g2: Tensor, g3: Tensor) -> Tensor:
         return ops.cn_gather_backward(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off, self.flags,

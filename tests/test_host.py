@@ -62,7 +62,7 @@ def test_entries_reject_bad_arguments_before_any_launch(hiplib):
     assert hiplib.ocn_cn_flags(p, p, p, p, NULL, NULL, NULL, 0, NULL, 0, p, p, NULL, -1, 10, p, p, 0, p, p, NULL, p, NULL, NULL, NULL) == E
     assert hiplib.ocn_cn_flags(p, p, NULL, NULL, NULL, NULL, NULL, 0, NULL, 0, p, p, NULL, 4, 10, p, p, 0, p, p, NULL, p, NULL,
                                NULL, NULL) == E                                                    # neither a CSR nor bit rows for T1
-    assert hiplib.ocn_cn_gather(p, p, p, p, NULL, 4, p, p, NULL, p, p, 0, 0, p, p, p, NULL, NULL, NULL, NULL, NULL, NULL) == E   # H = 0
+    assert hiplib.ocn_cn_gather(p, p, p, p, NULL, 4, p, p, NULL, p, p, 0, 0, p, p, p, NULL, NULL, NULL, NULL, NULL, NULL, NULL) == E   # H = 0
     assert hiplib.ocn_order_by_node_finish(p, 4, 0, p, p, NULL) == E
 
 

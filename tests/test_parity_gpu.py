@@ -1502,3 +1502,48 @@ def test_walk_route_on_a_dense_graph(hiplib):
     st = CNState(adj, None, None, e.to(DEV), walk=True)
     m2 = st.materialize(2)
     assert spm_equal(m2, oc2) and m2.storage.value().cpu().tolist() == oc2.val.tolist()
+
+
+@pytest.mark.parametrize("H,B,lnnn", [(64, 20000, True), (64, 1500, False), (256, 4096, True), (32, 3000, True)])
+def test_cn7_full_rows_share_the_row_sum(hiplib, monkeypatch, H, B, lnnn):
+    """ogbl-ddi's regime (dense graph, A² full): a candidate whose whole source row is cn2 takes xcn2 = (A·h)[source]
+    from ONE SpMM instead of summing the row again (ocn_cn_gather `rowsum`) — the same additions in the same order, so
+    pooled vectors and scores are bit-equal to the plain evaluation; on every pooling kernel (packed, one wave per row,
+    hub rows longer than 1024); the oracle agrees on the small batches."""
+    from ocn_amd import ops
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import CNState, adjoverlap
+    n = 1600
+    oadj = make_graph(n, 500, 1500, seed=11, clique_frac=0.2, isolated=5)
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    assert adj.max_rowcount() > 1024 and adj2.nnz() * 2 > n * n
+    e = batch(oadj, B, 3).to(DEV)
+    torch.manual_seed(H)
+    x = torch.randn(n, H, device=DEV)
+    pred = predictor_dict["cn7"](H, H, 1, 3, 0.0, 0.0, lnnn).eval().to(DEV)
+    args = SimpleNamespace(sum=2.74)
+    st = CNState(adj, adj, adj2, e)
+    rows = adj._rowptr[1:] - adj._rowptr[:-1]
+    full = (st.cnt2.long() == rows[e[0]]) & (rows[e[0]] > 0)
+    assert full.float().mean().item() > 0.5                      # the regime the shortcut is for
+    w = st.weights_cn7(args.sum)
+    plain = st.gather(w, x)
+    shared = st.gather(w, x, rowsum=ops.spmm_csr(adj._rowptr, adj._col, x))
+    for a, b in zip(plain, shared):
+        assert torch.equal(a, b)
+
+    def score():
+        with torch.no_grad():
+            return pred(x, adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e), e, args)
+    monkeypatch.setattr(ops, "share_full_rows", False)
+    ref = score()
+    assert getattr(pred, "_rowsum_cache", None) is None
+    monkeypatch.setattr(ops, "share_full_rows", True)
+    got = score()
+    assert pred._rowsum_cache is not None and torch.equal(got, ref)
+    if B <= 3000:                                                # (the column weights are the whole batch's: no sub-batch check)
+        ec = e.cpu()
+        oref = O.cn7_forward({k: v.detach().cpu() for k, v in pred.state_dict().items()}, x.cpu(), O.adjoverlap(oadj, oadj, ec),
+                             O.adjoverlap(oadj, O.adj2_sparse(oadj), ec), ec, args.sum, lnnn)
+        assert close(got, oref)
