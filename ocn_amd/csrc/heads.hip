@@ -468,12 +468,23 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
     return m;
   };
 
+  // Tiles go to the workgroups in SNAKE order (round q: q G + b on even rounds, q G + G - 1 - b on odd ones): the rows are
+  // class-major, so tile cost falls with the tile index (all three branches: 169 k cycles, xcn2lin + xijlin: 106 k, xijlin
+  // only: 52 k) — the workgroup that drew a heavy tile first gets the lightest one next, instead of heavy + medium landing on
+  // the first workgroups (collab shape: slowest workgroup 275 k -> 221 k cycles).
+  auto tile_at = [&](i64 q) -> i64 {
+    const i64 G = gridDim.x;
+    const i64 t = q * G + ((q & 1) ? G - 1 - (i64)blockIdx.x : (i64)blockIdx.x);
+    return t < n_tiles ? t : -1;
+  };
 #pragma unroll 1
-  for (i64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+  for (i64 round = 0;; ++round) {
+    const i64 tile = tile_at(round);
+    if (tile < 0) break;              // (only a last, partial round has tiles past the end: nothing follows it)
     const i64 slot = tile * HD_ROWS + 32 * w + r;
     const bool live = slot < a.B;
     const int wgA = tile_runs(tile, 0), wgB = tile_runs(tile, 1);
-    const i64 ntile = tile + gridDim.x < n_tiles ? tile + gridDim.x : tile;       // (past the end: this tile's rows once more)
+    const i64 ntile = tile_at(round + 1) >= 0 ? tile_at(round + 1) : tile;        // (past the end: this tile's rows once more)
     __syncthreads();                  // s_vec is written; nobody reads the previous tile's ring slots any more
     HD_STAMP(0);
 
