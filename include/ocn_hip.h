@@ -41,7 +41,9 @@ int ocn_abi_version(void);
 
 /* Scratch bytes the scan entries need for `n` items.  The workspace must be ZERO when first handed to the library
  * (the caller zeroes it once, when it allocates it); every entry leaves it zero again, so it can be reused from call
- * to call — inputs beyond one tile are scanned by a single launch whose tiles chain through this state. */
+ * to call — inputs beyond one tile are scanned by a single launch whose tiles chain through this state.  A workspace
+ * that is NOT zero breaks the chain: the launch then ends in a GPU trap (the process aborts) after a bounded wait —
+ * never in a hang, and never in prefix sums that are silently wrong. */
 int64_t ocn_scan_workspace_bytes(int64_t n);
 
 /* Zero up to 8 device arrays (4-byte aligned, byte counts multiples of 4) with one launch: the per-batch reset of

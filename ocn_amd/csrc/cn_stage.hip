@@ -99,7 +99,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
       else { b0 = rowptrT1[j]; db = rowptrT1[j + 1] - b0; }
       if (HAS_T2) {
         if (bmT2) bm_row = bmT2 + j * bm_stride;
-        else { c0 = rowptrT2[j]; dc = rowptrT2[j + 1] - c0; }
+        if (rowptrT2) { c0 = rowptrT2[j]; dc = rowptrT2[j + 1] - c0; }      // (with bit rows too: a FULL row needs no probe at all)
       }
       base = off[e];
     }
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
     const bool t1_lds = db <= T1_CAP;
     if (t1_lds)
       for (i64 q = gl; q < db; q += G) s_t1[g][q] = colT1[b0 + q];
-    const bool t2_full = HAS_T2 && !bmT2 && dc == n_cols;   // a full row (dense A², e.g. ddi) contains every column
+    const bool t2_full = HAS_T2 && rowptrT2 && dc == n_cols;   // a full row (dense A², e.g. ddi) contains every column
     if (HAS_T2 && !t2_full && !bmT2) {
       if (dc > OCN_WAVE) {
 #pragma unroll
@@ -132,9 +132,9 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
       f2 = (k & 1) == 0;
 #else
       if (HAS_T2) {
-        if (bmT2) f2 = (bm_row[k >> 5] >> (k & 31)) & 1u;    // one probe
-        else f2 = t2_full ? true
-                          : (dc > OCN_WAVE ? sampled_has(&s_t2[g][0], colT2 + c0, dc, k) : sorted_has(&s_t2[g][0], dc, k));
+        if (t2_full) f2 = true;
+        else if (bmT2) f2 = (bm_row[k >> 5] >> (k & 31)) & 1u;    // one probe
+        else f2 = dc > OCN_WAVE ? sampled_has(&s_t2[g][0], colT2 + c0, dc, k) : sorted_has(&s_t2[g][0], dc, k);
       }
 #endif
 #ifndef OCN_X_NOFLAGS

@@ -155,7 +155,7 @@ struct PrepExtra {
 // to finish clears the state, so the workspace is left as it was found: ZERO (ocn_scan_workspace_bytes; the
 // caller zeroes it once, when it allocates it).  state[0] = ticket, state[1] = finished tiles, state[2 + t] = tile t.
 #define SCAN_READY (1ull << 63)
-#define SCAN_SPIN_MAX (1 << 22)     /* bounded polling: a stale workspace gives wrong numbers, never a hang */
+#define SCAN_SPIN_MAX (1 << 24)     /* polls of one predecessor granule before the launch gives up — loudly (below) */
 template <typename Op, typename Extra = NoExtra>
 __global__ __launch_bounds__(OCN_BLOCK) void scan_chained(Op op, i64 n, i64* __restrict__ out, u64* __restrict__ state,
                                                           i64 nt, const Extra extra = Extra()) {
@@ -168,6 +168,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void scan_chained(Op op, i64 n, i64* __r
   if (threadIdx.x == 0) s_tile = (i64)atomicAdd(&state[0], 1ull);
   __syncthreads();
   const i64 t = s_tile;
+  if (t < 0 || t >= nt) __builtin_trap();     // a ticket outside the launch: the workspace was not zero (caller's contract)
   const i64 base = t * SCAN_TILE + (i64)threadIdx.x * SCAN_IPT;      // thread-contiguous items: prefix order = item order
   i64 v[SCAN_IPT];
   i64 s = 0;
@@ -187,11 +188,18 @@ __global__ __launch_bounds__(OCN_BLOCK) void scan_chained(Op op, i64 n, i64* __r
       const i64 p = p0 + threadIdx.x;
       u64 w = SCAN_READY;
       if (p < t) {
+        // Tickets are drawn in order, so every tile p < t belongs to a workgroup that is already running and publishes its
+        // granule before it waits for anything itself (tile 0 waits for nobody, tile p only for tiles < p): with a ZERO
+        // workspace (the caller's contract) the wait always ends.  A workspace that was not zero can leave a granule that
+        // never turns ready; the poll is bounded so that this cannot hang the GPU, and giving up is a trap (the process
+        // aborts with a GPU exception) rather than a prefix sum made of whatever was read last — wrong offsets would
+        // otherwise reach the flag layout, the processing order and the column lists without any sign.
         int spins = 0;
         do {
           w = __hip_atomic_load(&state[2 + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (!(w & SCAN_READY)) __builtin_amdgcn_s_sleep(1);
         } while (!(w & SCAN_READY) && ++spins < SCAN_SPIN_MAX);
+        if (!(w & SCAN_READY)) __builtin_trap();
       }
       prefix += (i64)(w & ~SCAN_READY);
     }
