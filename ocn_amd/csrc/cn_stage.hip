@@ -99,7 +99,8 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
       else { b0 = rowptrT1[j]; db = rowptrT1[j + 1] - b0; }
       if (HAS_T2) {
         if (bmT2) bm_row = bmT2 + j * bm_stride;
-        if (rowptrT2) { c0 = rowptrT2[j]; dc = rowptrT2[j + 1] - c0; }      // (with bit rows too: a FULL row needs no probe at all)
+        if (rowptrT2 && (LH || !bmT2)) { c0 = rowptrT2[j]; dc = rowptrT2[j + 1] - c0; }   // (small graphs with bit rows too: a FULL row — a dense A², ogbl-ddi —
+                                                                                  // needs no probe at all; on large graphs the two loads would only lengthen the chain)
       }
       base = off[e];
     }
@@ -204,9 +205,24 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
 // true hits (~1 % of the swept elements) plus the false positives — are queued in LDS and resolved in
 // bulk, one per thread, by binary search in the sorted CSR row; done inline that search would run with
 // a handful of live lanes on nearly every wave iteration.
-#define WALK_BM_BITS 18
+#ifndef OCN_X_WALK_BM_BITS
+#define OCN_X_WALK_BM_BITS 17
+#endif
+#define WALK_BM_BITS OCN_X_WALK_BM_BITS
 #define WALK_BM_WORDS (1 << (WALK_BM_BITS - 5))
-#define WALK_Q 1024           /* queue entries; flushed when half full, overflow resolves in place */
+#ifndef OCN_X_WALK_Q
+#define OCN_X_WALK_Q 1024
+#endif
+#define WALK_Q OCN_X_WALK_Q     /* queue entries; flushed when half full, overflow resolves in place */
+// The probed row itself is kept in LDS beside its bitmap (it passes through the workgroup's hands anyway when the bitmap
+// is built): resolving a queued element, and the cn1 test of the finalise step, are then binary searches in LDS —
+// ~10 dependent LDS reads instead of ~10 dependent trips to L2, which were two thirds of an item's chain of dependent
+// loads.  Rows longer than WALK_SET (hubs) keep the search in memory.  The room comes from halving the bitmap
+// (128 Kbit: twice the false positives, each now one cheap LDS search).
+#ifndef OCN_X_WALK_SET
+#define OCN_X_WALK_SET 4096
+#endif
+#define WALK_SET OCN_X_WALK_SET
 
 __device__ __forceinline__ unsigned walk_bit(int32_t v) { return ((unsigned)v * 2654435761u) >> (32 - WALK_BM_BITS); }
 __device__ __forceinline__ void walk_bm_add(unsigned* bm, int32_t v) {
@@ -226,6 +242,21 @@ __device__ __forceinline__ i64 sorted_find(const int32_t* __restrict__ a, i64 n,
     if (a[mid] < key) lo = mid + 1; else hi = mid;
   }
   return (lo < n && a[lo] == key) ? lo : -1;
+}
+
+// position of key in the probed row (LDS copy when it fits, else the CSR row in memory), or -1
+__device__ __forceinline__ i64 walk_set_find(const int32_t* s_set, const int32_t* __restrict__ set_g, i64 ds, int32_t key) {
+#if WALK_SET > 0
+  if (ds <= WALK_SET) {
+    int lo = 0, hi = (int)ds;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (s_set[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < (int)ds && s_set[lo] == key) ? lo : -1;
+  }
+#endif
+  return sorted_find(set_g, ds, key);
 }
 
 // batch slot of a work item: last slot with item_off[slot] <= item (item_off[0] = 0 <= item <
@@ -286,7 +317,7 @@ __device__ __forceinline__ int walk_item_rows(const i64* __restrict__ rowptrA, c
 // the set.
 template <typename Hit>
 __device__ __forceinline__ void walk_sweep(const int32_t* __restrict__ colA, const unsigned* s_bm, const int* s_pre,
-                                           const i64* s_r0, int total, const int32_t* __restrict__ set_g, i64 ds,
+                                           const i64* s_r0, int total, const int32_t* s_set, const int32_t* __restrict__ set_g, i64 ds,
                                            int32_t* s_qk, uint16_t* s_qr, int* s_nq, Hit hit) {
 #ifndef OCN_X_WALK_WU
 #define OCN_X_WALK_WU 8
@@ -312,7 +343,7 @@ __device__ __forceinline__ void walk_sweep(const int32_t* __restrict__ colA, con
         const int q = atomicAdd(s_nq, 1);
         if (q < WALK_Q) { s_qk[q] = m[u]; s_qr[q] = (uint16_t)row[u]; }
         else {                                                      // queue full (dense overlap): resolve in place
-          const i64 pos = sorted_find(set_g, ds, m[u]);
+          const i64 pos = walk_set_find(s_set, set_g, ds, m[u]);
           if (pos >= 0) hit(m[u], row[u], pos);
         }
       }
@@ -323,7 +354,7 @@ __device__ __forceinline__ void walk_sweep(const int32_t* __restrict__ colA, con
     if (flush) {
       const int nq = *s_nq < WALK_Q ? *s_nq : WALK_Q;
       for (int q = threadIdx.x; q < nq; q += WALK_THREADS) {
-        const i64 pos = sorted_find(set_g, ds, s_qk[q]);
+        const i64 pos = walk_set_find(s_set, set_g, ds, s_qk[q]);
         if (pos >= 0) hit(s_qk[q], (int)s_qr[q], pos);
       }
       __syncthreads();
@@ -335,6 +366,7 @@ __device__ __forceinline__ void walk_sweep(const int32_t* __restrict__ colA, con
 
 #define WALK_SHARED                                     \
   __shared__ unsigned s_bm[WALK_BM_WORDS];              \
+  __shared__ int32_t s_set[WALK_SET > 0 ? WALK_SET : 1]; \
   __shared__ int s_pre[WALK_ROWS + 1];                  \
   __shared__ i64 s_r0[WALK_ROWS];                       \
   __shared__ int32_t s_r[WALK_ROWS];                    \
@@ -383,14 +415,18 @@ __global__ __launch_bounds__(WALK_THREADS) void cn_walk_rev_kernel(
     const i64 p_lo = (item - rev_off[slot]) * WALK_REV_CHUNK;
     const int nm = (int)(((p_lo + WALK_REV_CHUNK) < db ? (p_lo + WALK_REV_CHUNK) : db) - p_lo);
     const int32_t* ni_g = colA + a0;
-    for (i64 q = threadIdx.x; q < da; q += WALK_THREADS) walk_bm_add(s_bm, ni_g[q]);
+    for (i64 q = threadIdx.x; q < da; q += WALK_THREADS) {
+      const int32_t v = ni_g[q];
+      walk_bm_add(s_bm, v);
+      if (q < WALK_SET) s_set[q] = v;
+    }
     int total = walk_item_rows(rowptrA, colA, b0 + p_lo, nm, s_pre, s_r0, s_r, s_ctot);
 #ifdef OCN_X_WALK_NOSWEEP   /* timing experiment: per-item overhead only */
     total = 0;
 #endif
     if (base + da > cap) total = 0;
     int32_t* wrow = wc + base;
-    walk_sweep(colA, s_bm, s_pre, s_r0, total, ni_g, da, s_qk, s_qr, &s_nq,
+    walk_sweep(colA, s_bm, s_pre, s_r0, total, s_set, ni_g, da, s_qk, s_qr, &s_nq,
                [wrow](int32_t, int, i64 pos) { atomicAdd(wrow + pos, 1); });
     __syncthreads();
   }
@@ -421,7 +457,11 @@ __global__ __launch_bounds__(WALK_THREADS) void cn_walk_kernel(
     const bool rev = walk_reverse(nds, i, j, da, db);      // workgroup-uniform
     const int32_t* nj_g = colA + b0;
 #ifndef OCN_X_WALK_NOBM
-    for (i64 q = threadIdx.x; q < db; q += WALK_THREADS) walk_bm_add(s_bm, nj_g[q]);
+    for (i64 q = threadIdx.x; q < db; q += WALK_THREADS) {
+      const int32_t v = nj_g[q];
+      walk_bm_add(s_bm, v);
+      if (q < WALK_SET) s_set[q] = v;
+    }
 #endif
     const i64 n_chunks = (da + WALK_CHUNK - 1) / WALK_CHUNK;
     const i64 cg = walk_group(nds, i, da);
@@ -441,7 +481,7 @@ __global__ __launch_bounds__(WALK_THREADS) void cn_walk_kernel(
 #endif
     if (rev) total = 0;
     int* walks_of = s_walks;
-    walk_sweep(colA, s_bm, s_pre, s_r0, total, nj_g, db, s_qk, s_qr, &s_nq,
+    walk_sweep(colA, s_bm, s_pre, s_r0, total, s_set, nj_g, db, s_qk, s_qr, &s_nq,
                [walks_of](int32_t, int row, i64) { atomicAdd(walks_of + row, 1); });
     __syncthreads();
 #ifndef OCN_X_WALK_NOFIN
@@ -451,7 +491,7 @@ __global__ __launch_bounds__(WALK_THREADS) void cn_walk_kernel(
       if (t < nk) {
         const int32_t k = s_r[t];
         const int walks = rev ? (in_cap ? wc[base + p_lo + t] : 0) : s_walks[t];
-        f1 = walk_bm_maybe(s_bm, k) && sorted_has(nj_g, db, k);
+        f1 = walk_bm_maybe(s_bm, k) && walk_set_find(s_set, nj_g, db, k) >= 0;
         f2 = walks > 0;
         if (in_cap) {
           flags[base + p_lo + t] = (uint8_t)((f1 ? OCN_F_CN1 : 0u) | (f2 ? OCN_F_CN2 : 0u));
