@@ -377,7 +377,8 @@ __device__ __forceinline__ void walk_sweep(const int32_t* __restrict__ colA, con
   __shared__ i64 s_slot, s_item
 
 // draw the next work item (ticket counter) and find its batch slot, while the other waves clear the bitmap
-#define WALK_NEXT_ITEM(TICKET, ITEM_OFF)                                                             \
+#define WALK_NEXT_ITEM(TICKET, ITEM_OFF) WALK_NEXT_ITEM_X(TICKET, ITEM_OFF, (void)0)
+#define WALK_NEXT_ITEM_X(TICKET, ITEM_OFF, ONEXIT)                                                   \
   if (w == 0) {                                                                                      \
     i64 t = 0;                                                                                       \
     if (lane == 0) t = atomicAdd((TICKET), 1);                                                       \
@@ -389,7 +390,7 @@ __device__ __forceinline__ void walk_sweep(const int32_t* __restrict__ colA, con
   }                                                                                                  \
   __syncthreads();                                                                                   \
   const i64 item = s_item;                                                                           \
-  if (item >= n_items) break;                                                                        \
+  if (item >= n_items) { ONEXIT; break; }                                                            \
   const i64 slot = s_slot;                                                                           \
   const i64 e = order ? order[slot] : slot;                                                          \
   const i64 i = src[e], j = dst[e];                                                                  \
@@ -432,6 +433,13 @@ __global__ __launch_bounds__(WALK_THREADS) void cn_walk_rev_kernel(
   }
 }
 
+#ifdef OCN_X_WALK_STAMPS
+__device__ unsigned long long g_walk_stamps[256 * 8];
+extern "C" int ocn_debug_walk_stamps(unsigned long long* out, int reset) {
+  if (reset) { static unsigned long long z[256 * 8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_walk_stamps), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_stamps), 256 * 8 * sizeof(unsigned long long));
+}
+#endif
 // Forward sweep.  Work item = (batch row, group of <= WALK_WAVES consecutive 64-row chunks of N(i));
 // items are enumerated through the exclusive scan chunk_off[] so that a hub source node is spread
 // over many workgroups instead of serialising one, while a light row is a single item (one round of
@@ -452,8 +460,18 @@ __global__ __launch_bounds__(WALK_THREADS) void cn_walk_kernel(
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (blockIdx.x == 0 && threadIdx.x == 0 && off[B] > cap) atomicOr(status, 1);
   const i64 n_items = chunk_off[B];
+#ifdef OCN_X_WALK_STAMPS   /* diagnostic build: where an item's time goes (tools/walkstamps.py) */
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define WSTAMP(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tn = __builtin_amdgcn_s_memtime(); tph[k] += tn - tprev; tprev = tn; } while (0)
+#define WSTAMP_OUT() do { if (threadIdx.x == 0 && blockIdx.x < 256) for (int q = 0; q < 6; ++q) g_walk_stamps[blockIdx.x * 8 + q] += tph[q]; } while (0)
+#else
+#define WSTAMP(k) do {} while (0)
+#define WSTAMP_OUT() do {} while (0)
+#endif
   for (;;) {
-    WALK_NEXT_ITEM(status + 1, chunk_off);
+    if (w == 0) { WSTAMP(5); }
+    WALK_NEXT_ITEM_X(status + 1, chunk_off, WSTAMP_OUT());
+    WSTAMP(0);
     const bool rev = walk_reverse(nds, i, j, da, db);      // workgroup-uniform
     const int32_t* nj_g = colA + b0;
 #ifndef OCN_X_WALK_NOBM
@@ -480,10 +498,12 @@ __global__ __launch_bounds__(WALK_THREADS) void cn_walk_kernel(
     total = 0;
 #endif
     if (rev) total = 0;
+    WSTAMP(1);
     int* walks_of = s_walks;
     walk_sweep(colA, s_bm, s_pre, s_r0, total, s_set, nj_g, db, s_qk, s_qr, &s_nq,
                [walks_of](int32_t, int row, i64) { atomicAdd(walks_of + row, 1); });
     __syncthreads();
+    WSTAMP(2);
 #ifndef OCN_X_WALK_NOFIN
     {                                          // finalise: one row per thread
       const int t = threadIdx.x;
@@ -509,7 +529,14 @@ __global__ __launch_bounds__(WALK_THREADS) void cn_walk_kernel(
       }
     }
 #endif
+    WSTAMP(3);
     __syncthreads();
+    WSTAMP(4);
+    if (threadIdx.x == 0) {
+#ifdef OCN_X_WALK_STAMPS
+      if (blockIdx.x < 256) g_walk_stamps[blockIdx.x * 8 + 6] += 1;
+#endif
+    }
   }
 }
 

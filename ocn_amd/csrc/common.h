@@ -89,7 +89,10 @@ __device__ __forceinline__ i64 block_excl_scan(i64 v, i64* sh, i64* total) {
 // sweeps about WALK_ITEM_ELEMS elements: a light row (most of a batch) is one item instead of one per
 // 64 neighbours — the per-item set-up (ticket, slot search, row pointers, N(j) bitmap) is what such
 // items cost — while a hub row still spreads over many workgroups.
-#define WALK_ITEM_ELEMS 16384
+#ifndef OCN_X_WALK_ITEM_ELEMS
+#define OCN_X_WALK_ITEM_ELEMS 16384
+#endif
+#define WALK_ITEM_ELEMS OCN_X_WALK_ITEM_ELEMS
 #define WALK_GROUP_MAX 8      /* chunks per forward item: one per wave of the 512-thread workgroup */
 __device__ __forceinline__ i64 walk_group(const i64* __restrict__ nds, i64 i, i64 di) {
   const i64 chunks = (di + WALK_CHUNK - 1) / WALK_CHUNK;
