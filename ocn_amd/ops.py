@@ -19,7 +19,7 @@ FLAGS_NOSYNC_LIMIT = 1 << 30     # bytes of flag buffer we are willing to over-a
 validate_indices = True          # bounds-check candidate edges on the host side (one sync per batch)
 stage_timer = None               # optional object with .mark(name): bench.py records HIP events between stages
 LN_WIDTHS = (16, 32, 64, 128, 256, 512)   # row widths of the lane-group kernels (LayerNorm, pooling backward)
-a1_bitmap_max_bytes = 64 << 20   # keep A itself as dense bit rows too when they fit this (ogbl-ddi: 2.3 MB): cn1 membership = one probe
+a1_bitmap_max_bytes = int(os.environ.get("OCN_A1_BITMAP_MAX_BYTES", 64 << 20))   # keep A itself as dense bit rows too when they fit this (ogbl-ddi: 2.3 MB): cn1 membership = one probe
 a2_bitmap_max_bytes = 16 << 30   # keep A·B also as dense bit rows when n_rows * n_cols / 8 fits this budget
 skip_zero_rows = True            # heads: skip the layers whose pooled input row is all zero (class-major rows)
 skip_zero_min_share = 0.15       # ... and when fewer than this share of the head rows could be skipped (probed asynchronously)
