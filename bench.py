@@ -368,7 +368,7 @@ def main():
     # N > 1: two batches in flight — the intersection pass of batch t + 1 is enqueued before batch t waits for its
     # histogram all-reduce (predictor.begin / .finish), so the collective runs beside compute instead of stalling the
     # stream.  The timed loop still begins and finishes exactly K batches between its barriers.
-    pipelined = (world > 1 or args.rehearse_collectives) and not args.graph
+    pipelined = not args.graph                     # N = 1 too: phase A of batch t + 1 runs on a second stream beside phase B of batch t
     ahead = [None, -1]                             # [token of the batch already begun, its index]
 
     def begin(it):
@@ -416,10 +416,16 @@ def main():
         step(i)
         if i % 4 == 3:
             torch.cuda.synchronize()
-    for i in range(args.warmup):
-        step(i)
+    if pipelined and args.warmup > 0:              # the W warm-up steps run the timed loop's own code path (second stream included)
+        from ocn_amd.pipeline import pipelined_shard_loop
+        with torch.no_grad():
+            pipelined_shard_loop(begin, lambda tok: pred.finish(h, tok, wl["args"]), args.warmup, B_total, gather_at_end=True)
+        torch.cuda.synchronize()
+    else:
+        for i in range(args.warmup):
+            step(i)
 
-    def timed_loop(steps, timer):
+    def timed_loop(steps, timer, overlap=None):
         """EXACTLY `steps` steps between two barrier + synchronize brackets; returns (seconds, host enqueue seconds)."""
         ops.stage_timer = timer
         torch.cuda.synchronize()
@@ -459,8 +465,11 @@ def main():
             from ocn_amd.pipeline import pipelined_shard_loop
             with torch.no_grad():
                 scores, pattern[0] = pipelined_shard_loop(begin, lambda tok: pred.finish(h, tok, wl["args"]), steps, B_total,
-                                                          gather_at_end=True, before_step=before_step, after_step=after_step)
+                                                          gather_at_end=True, before_step=before_step, after_step=after_step,
+                                                          overlap=overlap)
             out = scores[-1]
+            if world == 1 and not args.rehearse_collectives:
+                pattern[0] = "single rank: no collective; " + pattern[0]
         else:
             for it in range(steps):
                 before_step(it)
@@ -485,6 +494,18 @@ def main():
 
     timer = None if args.no_stage_timers else StageTimer(pool=40 * (args.steps // args.timer_every + 1))
     dt, t_launch, out = timed_loop(args.steps, timer)
+    pattern_main = pattern[0]
+    # The same loop on ONE stream (untimed for `value`): per-kernel durations without the other stream's kernels beside
+    # them — under the two-stream overlap a launch's duration includes what it yields to its neighbour — and the step time
+    # the overlap is measured against.  Reported next to the timed region's own figures, never instead of them.
+    timer1, dt1 = None, None
+    overlapped = pipelined and "second HIP stream" in pattern_main
+    if overlapped and not args.no_stage_timers:
+        n1 = min(args.steps, 40)
+        timer1 = StageTimer(pool=40 * (n1 // args.timer_every + 1))
+        dt1, _, _ = timed_loop(n1, timer1, overlap=False)
+        dt1 /= n1
+        pattern[0] = pattern_main
     # second leg: the per-batch id check left on (the drivers' literal loop: one host sync per batch)
     dt_val = None
     if not args.no_validate_leg and not args.graph:
@@ -537,7 +558,10 @@ def main():
                                      "shared rows are served by L2; traffic = PMC 2*FETCH_SIZE + WRITE_SIZE of the "
                                      "committed profile")
                 stages[k]["compulsory_GBps"] = roofs[k]["achieved"]
-            dom = max((k for k in ("cn_flags", "cn_gather", "linear") if k in stages), key=lambda k: per_step[k])
+            stages1 = {k: dict(ms=v[0], launches=v[1]) for k, v in (timer1.totals() if timer1 else {}).items()}
+            # the dominant kernel: by its time per step on one stream (under overlap the two streams' durations are not additive)
+            base = stages1 if stages1 else stages
+            dom = max((k for k in ("cn_flags", "cn_gather", "linear") if k in base), key=lambda k: base[k]["ms"] * base[k]["launches"])
             roof_hbm = roofs.get("cn_gather")
             if "linear" in stages:
                 # MFMA work of the MLP heads per launch.  The fused kernel (ocn_heads_fused, H >= 128) multiplies a row by
@@ -581,6 +605,15 @@ def main():
                                            "Linear(H,H) of the reference folded to 8 panels) against the dense 16-bit MFMA peak; "
                                            "f32_equivalent_* = the same work counted once per f32 product.  MFMA-busy counters: "
                                            "profiles/r03_heads_pmc.json.  Head: " + head_layout(pred))
+            for k, rk in (("cn_flags", "cn_flags"), ("cn_gather", "cn_gather"), ("linear", "heads")):
+                if rk in roofs and k in stages1:
+                    t1 = stages1[k]["ms"]
+                    roofs[rk]["avg_launch_ms_one_stream"] = t1
+                    roofs[rk]["frac_one_stream"] = roofs[rk]["frac"] * roofs[rk]["avg_launch_ms"] / t1
+                    stages[k]["ms_one_stream"] = t1
+                    roofs[rk]["note"] += ("  avg_launch_ms / achieved / frac are measured inside the timed region, where the intersection pass "
+                                          "of the next batch runs on a second stream beside this kernel; *_one_stream = the same launch "
+                                          "with the streams serialised.")
             roof = roofs["heads"] if dom == "linear" else roofs[dom]
         cpu, err, ref_scale = None, None, None
         if world == 1 and not args.no_cpu_baseline:
@@ -615,6 +648,8 @@ def main():
             "roofline": roof, "roofline_hbm_kernel": roof_hbm, "rooflines": roofs, "cpu_baseline": cpu,
             "value_trained_innerprod": None if dt_tr is None else B_total / dt_tr,
             "ms_per_step_trained_innerprod": None if dt_tr is None else dt_tr * 1e3,
+            "value_one_stream": None if dt1 is None else B_total / dt1,
+            "ms_per_step_one_stream": None if dt1 is None else dt1 * 1e3,
             "value_validate_per_batch": None if dt_val is None else B_total / dt_val,
             "ms_per_step_validate_per_batch": None if dt_val is None else dt_val * 1e3,
             "stages": stages,

@@ -538,6 +538,7 @@ class _CNPredictorBase(nn.Module):
     def finish(self, x, token, args=None):
         """Phase B: class order (beside the collective), wait for the histogram sum, weights, pooling, heads."""
         st, handle = token
+        ops._mark("begin")                     # (stage timers: this phase may run on another stream than phase A did)
         self._class_order(st, x)
         if handle is not None:
             from .dist import allreduce_hist_finish

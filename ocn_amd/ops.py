@@ -29,6 +29,8 @@ walk_two_sided = True            # walk route: sweep each candidate from its che
 walk_share_min = 2               # walk route, B <= 4096: candidates sharing a source are swept together from this group size on (0 = never)
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 heavy_first = True               # ... and the pooling (H = 256) visits its slot groups longest first (ocn_cn_flags' gcost -> ocn_gather_schedule)
+overlap_min_batch = 2048         # ... from this many candidates per batch (Cora-sized batches: the two event hand-offs cost more than the overlap gives)
+overlap_streams = os.environ.get("OCN_ONE_STREAM", "0") != "1"   # scoring loops: phase A of batch t + 1 on a second stream beside phase B of batch t (pipeline.overlapped_steps)
 share_full_rows = True           # cn7 on a dense graph: candidates whose whole source row is cn2 copy (A h)[source] (ocn_cn_gather `rowsum`)
 deterministic_backward = os.environ.get("OCN_ATOMIC_BACKWARD", "0") != "1"   # pooling backward node by node in a fixed order (ocn_cn_gather_backward_det); else fp32 atomics
 

@@ -1066,6 +1066,45 @@ def test_two_phase_scoring_keeps_two_batches_in_flight(case, name):
         pred.begin(x, case.adj, *handles(batches[0]), batches[0])         # autograd on: not the scoring path
 
 
+@pytest.mark.parametrize("name", ["cn5", "cn7"])
+def test_two_stream_scoring_loop_equals_one_stream(case, name, monkeypatch):
+    """pipeline.overlapped_steps / score_edges: phase A of batch t + 1 on a second HIP stream beside phase B of batch t,
+    ordered by events (B of t after A of t; A of t + 2 after B of t: they share a scratch set) — twelve ragged batches
+    score exactly as on one stream and as forward() does, twice in a row (the side stream is reused)."""
+    from ocn_amd import ops
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.pipeline import overlapped_steps, score_edges
+    from ocn_amd.utils import adjoverlap
+    H = 64
+    torch.manual_seed(case.seed + 5)
+    x = torch.randn(case.n, H, device=DEV)
+    pred = predictor_dict[name](H, H, 1, 3, 0.0, 0.0, True).to(DEV).eval()
+    args = SimpleNamespace(sum=0.7)
+    g = torch.Generator().manual_seed(9)
+    batches = [case.e.to(DEV)[:, torch.randperm(case.B, generator=g).to(DEV)][:, : max(case.B - 5 * q, 1)].contiguous() for q in range(12)]
+
+    def handles(e):
+        return adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e)
+
+    def begin(it):
+        return pred.begin(x, case.adj, *handles(batches[it]), batches[it], slot=it)
+
+    with torch.no_grad():
+        ref = [pred(x, case.adj, *handles(e), e, args).clone() for e in batches]
+        for overlap in (True, False, True):
+            outs = [o.clone() for o in overlapped_steps(begin, lambda tok: pred.finish(x, tok, args), len(batches), overlap=overlap)]
+            torch.cuda.synchronize()
+            for a, b in zip(outs, ref):
+                assert torch.equal(a, b)
+        edges = torch.cat(batches, 1).t().contiguous()              # [n, 2], the split_edge layout
+        bs = max(case.B // 3, 1)
+        monkeypatch.setattr(ops, "overlap_min_batch", 0)
+        two = score_edges(pred, x, case.adj, case.adj2, edges, bs, args)
+        monkeypatch.setattr(ops, "overlap_streams", False)
+        one = score_edges(pred, x, case.adj, case.adj2, edges, bs, args)
+    assert torch.equal(two, one)
+
+
 def test_order_sensitive_column_sum_known_answer_on_the_gpu(hiplib):
     """tests/golden/order_sensitive_colsum.json (hand-derived): five entries in one column whose fp32 sum is 2^25 only in
     ascending batch-row order (2^25 + 4 with the small entries first, or with one rounding of the exact sum)."""
