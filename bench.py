@@ -499,7 +499,7 @@ def main():
     # them — under the two-stream overlap a launch's duration includes what it yields to its neighbour — and the step time
     # the overlap is measured against.  Reported next to the timed region's own figures, never instead of them.
     timer1, dt1 = None, None
-    overlapped = pipelined and "second HIP stream" in pattern_main
+    overlapped = pipelined and "HIP stream" in pattern_main
     if overlapped and not args.no_stage_timers:
         n1 = min(args.steps, 40)
         timer1 = StageTimer(pool=40 * (n1 // args.timer_every + 1))

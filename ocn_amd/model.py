@@ -519,13 +519,14 @@ class _CNPredictorBase(nn.Module):
     # begin(t + 1) is enqueued before finish(t): in the edge-sharded mode the histogram all-reduce of batch t then
     # runs beside the intersection pass of batch t + 1 instead of stalling the stream (ocn_amd/dist.py; bench.py).
     def begin(self, x, adj, cn1, cn2, tar_ei, slot: int = 0):
-        """Phase A: the intersection pass of one batch (scratch set ``slot`` & 1 — a batch in phase A must not share
-        buffers with the one still in phase B) and, sharded, the START of the histogram sum.  Returns a token."""
+        """Phase A: the intersection pass of one batch (scratch set ``slot`` mod ``ops.overlap_depth`` — a batch in phase A
+        must not share buffers with the ones still in flight) and, sharded, the START of the histogram sum.  Returns a token."""
         if self.training or torch.is_grad_enabled():
             raise RuntimeError("begin / finish is the no-grad scoring path: call .eval() under torch.no_grad()")
-        if not hasattr(self, "_ws_slots"):
-            self._ws_slots = [dict(), dict()]
-        st = fuse(cn1, cn2, tar_ei, self._ws_slots[slot & 1], adj=adj)
+        n_sets = max(2, int(ops.overlap_depth))
+        if len(getattr(self, "_ws_slots", ())) != n_sets:
+            self._ws_slots = [dict() for _ in range(n_sets)]
+        st = fuse(cn1, cn2, tar_ei, self._ws_slots[slot % n_sets], adj=adj)
         handle = None
         if self._sharded:
             from .dist import allreduce_hist_start

@@ -29,6 +29,9 @@ walk_two_sided = True            # walk route: sweep each candidate from its che
 walk_share_min = 2               # walk route, B <= 4096: candidates sharing a source are swept together from this group size on (0 = never)
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 heavy_first = True               # ... and the pooling (H = 256) visits its slot groups longest first (ocn_cn_flags' gcost -> ocn_gather_schedule)
+overlap_depth = int(os.environ.get("OCN_OVERLAP_DEPTH", 3))   # scratch sets of a predictor = the most batches a scoring loop keeps in flight
+overlap_deep_max_batch = 4096    # ... which it does for batches up to this size (the drivers' 2 048-candidate walk-route batches: two intersection
+                                 # passes beside one pooling + heads; citation2 shape 3.96 -> 4.81 M edges/s); larger batches: two in flight
 overlap_min_batch = 2048         # ... from this many candidates per batch (Cora-sized batches: the two event hand-offs cost more than the overlap gives)
 overlap_streams = os.environ.get("OCN_ONE_STREAM", "0") != "1"   # scoring loops: phase A of batch t + 1 on a second stream beside phase B of batch t (pipeline.overlapped_steps)
 share_full_rows = True           # cn7 on a dense graph: candidates whose whole source row is cn2 copy (A h)[source] (ocn_cn_gather `rowsum`)

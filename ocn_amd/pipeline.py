@@ -93,10 +93,10 @@ def score_mrr_split(predictor, h: Tensor, adj, source: Tensor, target: Tensor, t
 _side_streams: dict = {}
 
 
-def _side_stream(index: int):
-    s = _side_streams.get(index)
+def _side_stream(index: int, q: int = 0):
+    s = _side_streams.get((index, q))
     if s is None:
-        s = _side_streams[index] = torch.cuda.Stream(device=index)
+        s = _side_streams[(index, q)] = torch.cuda.Stream(device=index)
     return s
 
 
@@ -124,34 +124,41 @@ def overlapped_steps(begin, finish, n_steps: int, before_step=None, after_step=N
                 after_step(it)
         return
     main = torch.cuda.current_stream()
-    side = _side_stream(main.device.index if main.device.index is not None else torch.cuda.current_device())
-    begun = [torch.cuda.Event(), torch.cuda.Event()]
-    done = [torch.cuda.Event(), torch.cuda.Event()]
-    side.wait_stream(main)
+    index = main.device.index if main.device.index is not None else torch.cuda.current_device()
+    # batches in flight: depth - 1 in phase A, one in phase B
+    depth = max(2, int(ops.overlap_depth)) if (batch is not None and batch <= ops.overlap_deep_max_batch) else 2
+    sides = [_side_stream(index, q) for q in range(depth - 1)]
+    begun = [torch.cuda.Event() for _ in range(depth)]
+    done = [torch.cuda.Event() for _ in range(depth)]
+    for sd in sides:
+        sd.wait_stream(main)
 
     def phase_a(it):
-        with torch.cuda.stream(side):
-            if it >= 2:
-                side.wait_event(done[it & 1])          # phase B of batch it - 2 read the scratch set this batch overwrites
+        sd = sides[it % (depth - 1)]
+        with torch.cuda.stream(sd):
+            if it >= depth:
+                sd.wait_event(done[it % depth])        # phase B of batch it - depth read the scratch set this batch overwrites
             tok = begin(it)
-            begun[it & 1].record(side)
+            begun[it % depth].record(sd)
         return tok
 
-    ahead = None
+    ahead = []                                             # tokens of the batches already in phase A, oldest first
     try:
         for it in range(n_steps):
             if before_step is not None:
                 before_step(it)
-            tok = ahead if ahead is not None else phase_a(it)
-            ahead = phase_a(it + 1) if it + 1 < n_steps else None
-            main.wait_event(begun[it & 1])
+            while len(ahead) < depth and it + len(ahead) < n_steps:
+                ahead.append(phase_a(it + len(ahead)))
+            tok = ahead.pop(0)
+            main.wait_event(begun[it % depth])
             out = finish(tok)
-            done[it & 1].record(main)
+            done[it % depth].record(main)
             yield out
             if after_step is not None:
                 after_step(it)
     finally:
-        main.wait_stream(side)
+        for sd in sides:
+            main.wait_stream(sd)
 
 
 def pipelined_shard_loop(begin, finish, n_steps: int, batch_total: int, group=None, gather_at_end: bool = True,
@@ -170,14 +177,16 @@ def pipelined_shard_loop(begin, finish, n_steps: int, batch_total: int, group=No
     if gather_at_end and batch_total % world != 0:
         gather_at_end = False                                  # ragged slices: per-batch gather pads and trims
     kept, outs, pending = [], [], None
-    streams = ""
+    streams, deep = "", 2
     if overlap is None:
         overlap = (bool(ops.overlap_streams) and torch.cuda.is_available() and torch.cuda.is_initialized()
                    and batch_total // max(world, 1) >= ops.overlap_min_batch)
     if overlap:
-        streams = "; phase A (intersection pass) of batch t + 1 on a second HIP stream beside phase B of batch t"
+        deep = max(2, int(ops.overlap_depth)) if batch_total // max(world, 1) <= ops.overlap_deep_max_batch else 2
+        streams = ("; phase A (intersection pass) of batch t + 1 on a second HIP stream beside phase B of batch t" if deep == 2 else
+                   f"; phase A (intersection pass) of batches t + 1 .. t + {deep - 1} on {deep - 1} more HIP streams beside phase B of batch t")
     it = -1
-    for loc in overlapped_steps(begin, finish, n_steps, before_step, None, overlap):
+    for loc in overlapped_steps(begin, finish, n_steps, before_step, None, overlap, batch=batch_total // max(world, 1)):
         it += 1
         if gather_at_end:
             kept.append(loc)
@@ -198,8 +207,8 @@ def pipelined_shard_loop(begin, finish, n_steps: int, batch_total: int, group=No
         allsc = gather_scores(torch.cat(kept, 0), len(kept) * batch_total, group)       # rank-major: [world][n_steps][per]
         w = allsc.shape[0] // (len(kept) * per)
         scores = allsc.view(w, len(kept), per, -1).permute(1, 0, 2, 3).reshape(len(kept), w * per, -1)
-        return scores, "two batches in flight (begin/finish), local scores kept, ONE all-gather closes the loop" + streams
-    return (torch.stack(outs, 0) if outs else None), "two batches in flight (begin/finish), one async all-gather per batch" + streams
+        return scores, f"{deep} batches in flight (begin/finish), local scores kept, ONE all-gather closes the loop" + streams
+    return (torch.stack(outs, 0) if outs else None), f"{deep} batches in flight (begin/finish), one async all-gather per batch" + streams
 
 
 class GraphedScorer:

@@ -1069,8 +1069,8 @@ def test_two_phase_scoring_keeps_two_batches_in_flight(case, name):
 @pytest.mark.parametrize("name", ["cn5", "cn7"])
 def test_two_stream_scoring_loop_equals_one_stream(case, name, monkeypatch):
     """pipeline.overlapped_steps / score_edges: phase A of batch t + 1 on a second HIP stream beside phase B of batch t,
-    ordered by events (B of t after A of t; A of t + 2 after B of t: they share a scratch set) — twelve ragged batches
-    score exactly as on one stream and as forward() does, twice in a row (the side stream is reused)."""
+    ordered by events (B of t after A of t; A of t + depth after B of t: they share a scratch set) — twelve ragged batches
+    score exactly as on one stream and as forward() does, with two and with three batches in flight (the side streams are reused)."""
     from ocn_amd import ops
     from ocn_amd.model import predictor_dict
     from ocn_amd.pipeline import overlapped_steps, score_edges
@@ -1091,8 +1091,9 @@ def test_two_stream_scoring_loop_equals_one_stream(case, name, monkeypatch):
 
     with torch.no_grad():
         ref = [pred(x, case.adj, *handles(e), e, args).clone() for e in batches]
-        for overlap in (True, False, True):
-            outs = [o.clone() for o in overlapped_steps(begin, lambda tok: pred.finish(x, tok, args), len(batches), overlap=overlap)]
+        for overlap, batch in ((True, None), (False, None), (True, 1), (True, None)):      # batch=1: the deep loop (three in flight)
+            outs = [o.clone() for o in overlapped_steps(begin, lambda tok: pred.finish(x, tok, args), len(batches), overlap=overlap,
+                                                        batch=batch)]
             torch.cuda.synchronize()
             for a, b in zip(outs, ref):
                 assert torch.equal(a, b)
