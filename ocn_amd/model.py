@@ -530,16 +530,22 @@ class _CNPredictorBase(nn.Module):
         handle = None
         if self._sharded:
             from .dist import allreduce_hist_start
-            # the whole interleaved buffer, no copy-out / copy-back of the packed word: the collective is hidden behind the
-            # next batch's intersection pass, its extra bytes are free, the two copies were not
-            handle = allreduce_hist_start(st.hist, self._shard_group, valued=True)
             st.sharded, st.shard_group = True, self._shard_group
+            if ops.shard_reduce_in_finish if ops.shard_reduce_in_finish is not None else ops._overlap_active:
+                handle = "late"                    # (started by finish(), on ITS stream: see there)
+            else:
+                # the whole interleaved buffer, no copy-out / copy-back of the packed word: the collective is hidden behind the
+                # next batch's intersection pass, its extra bytes are free, the two copies were not
+                handle = allreduce_hist_start(st.hist, self._shard_group, valued=True)
         return st, handle
 
     def finish(self, x, token, args=None):
         """Phase B: class order (beside the collective), wait for the histogram sum, weights, pooling, heads."""
         st, handle = token
         ops._mark("begin")                     # (stage timers: this phase may run on another stream than phase A did)
+        if isinstance(handle, str):            # "late": the collective starts here, the class ordering runs beside it, and the
+            from .dist import allreduce_hist_start      # next batch's phase A (another stream) fills the rest of the wait
+            handle = allreduce_hist_start(st.hist, self._shard_group, valued=True)
         self._class_order(st, x)
         if handle is not None:
             from .dist import allreduce_hist_finish

@@ -32,6 +32,12 @@ heavy_first = True               # ... and the pooling (H = 256) visits its slot
 overlap_depth = int(os.environ.get("OCN_OVERLAP_DEPTH", 3))   # scratch sets of a predictor = the most batches a scoring loop keeps in flight
 overlap_deep_max_batch = 4096    # ... which it does for batches up to this size (the drivers' 2 048-candidate walk-route batches: two intersection
                                  # passes beside one pooling + heads; citation2 shape 3.96 -> 4.81 M edges/s); larger batches: two in flight
+# Sharded scoring loops: where a batch's histogram all-reduce starts.  None = by the loop: in phase B (on the caller's stream, the
+# class ordering and the NEXT batch's phase A on the other stream fill the wait) when the loop overlaps two streams — started from
+# the side stream the collective cost 25 % of the step in the one-rank rehearsal (105 M against 140 M edges/s) — and in phase A (a
+# whole step ahead, hidden behind the next intersection pass in stream order) on one stream.  OCN_REDUCE_IN_FINISH=0|1 forces it.
+shard_reduce_in_finish = {"0": False, "1": True}.get(os.environ.get("OCN_REDUCE_IN_FINISH", ""), None)
+_overlap_active = False          # set by pipeline.overlapped_steps while it runs phase A on side streams
 overlap_min_batch = 2048         # ... from this many candidates per batch (Cora-sized batches: the two event hand-offs cost more than the overlap gives)
 overlap_streams = os.environ.get("OCN_ONE_STREAM", "0") != "1"   # scoring loops: phase A of batch t + 1 on a second stream beside phase B of batch t (pipeline.overlapped_steps)
 share_full_rows = True           # cn7 on a dense graph: candidates whose whole source row is cn2 copy (A h)[source] (ocn_cn_gather `rowsum`)

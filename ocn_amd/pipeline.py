@@ -143,6 +143,7 @@ def overlapped_steps(begin, finish, n_steps: int, before_step=None, after_step=N
         return tok
 
     ahead = []                                             # tokens of the batches already in phase A, oldest first
+    was_active, ops._overlap_active = ops._overlap_active, True      # (predictor.begin: the sharded collective then starts in phase B)
     try:
         for it in range(n_steps):
             if before_step is not None:
@@ -157,6 +158,7 @@ def overlapped_steps(begin, finish, n_steps: int, before_step=None, after_step=N
             if after_step is not None:
                 after_step(it)
     finally:
+        ops._overlap_active = was_active
         for sd in sides:
             main.wait_stream(sd)
 
