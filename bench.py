@@ -374,7 +374,7 @@ def main():
     def begin(it):
         mine = mines[it % NB]
         c1, c2 = cn_handles(wl, mine)
-        return pred.begin(h, adj, c1, c2, mine, slot=it)
+        return pred.begin(h, adj, c1, c2, mine, slot=it, args=wl["args"])
 
     def step(it=0, last=True):
         with torch.no_grad():

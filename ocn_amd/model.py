@@ -459,6 +459,7 @@ class _CNPredictorBase(nn.Module):
     ``nn.Sequential`` layouts are part of the checkpoint contract (state_dict keys)."""
     cndeg: Final[int]
     _xcn2_on_union = True          # pooled xcn2 lives on cn1 ∪ cn2 (cn5); cn7 overrides: raw cn2 only
+    _weights_need_args = False     # cn7: its column weights read ``args.sum``
 
     def __init__(self, in_channels, hidden_channels, out_channels, num_layers, dropout, edrop=0.0,
                  ln=False, cndeg=-1, use_xlin=False, tailact=False, twolayerlin=False, beta=1.0):
@@ -518,7 +519,7 @@ class _CNPredictorBase(nn.Module):
     # ---- two-phase scoring (eval, no grad) for loops that keep two batches in flight ---------------------------
     # begin(t + 1) is enqueued before finish(t): in the edge-sharded mode the histogram all-reduce of batch t then
     # runs beside the intersection pass of batch t + 1 instead of stalling the stream (ocn_amd/dist.py; bench.py).
-    def begin(self, x, adj, cn1, cn2, tar_ei, slot: int = 0):
+    def begin(self, x, adj, cn1, cn2, tar_ei, slot: int = 0, args=None):
         """Phase A: the intersection pass of one batch (scratch set ``slot`` mod ``ops.overlap_depth`` — a batch in phase A
         must not share buffers with the ones still in flight) and, sharded, the START of the histogram sum.  Returns a token."""
         if self.training or torch.is_grad_enabled():
@@ -537,11 +538,19 @@ class _CNPredictorBase(nn.Module):
                 # the whole interleaved buffer, no copy-out / copy-back of the packed word: the collective is hidden behind the
                 # next batch's intersection pass, its extra bytes are free, the two copies were not
                 handle = allreduce_hist_start(st.hist, self._shard_group, valued=True)
-        return st, handle
+        # Unsharded, the batch's histogram is complete when the intersection pass ends: the column weights — and, for a
+        # trained cn5 / cn6 (innerprod != 0), the order-exact column sums in front of them, 0.2 ms of latency-bound chains at
+        # the collab shape — belong to phase A, which the scoring loops run beside the previous batch's pooling and heads.
+        # (cn7's weights need ``args.sum``: pass ``args``.)
+        w = None
+        if handle is None and not self._sharded and (args is not None or not self._weights_need_args):
+            w = self._weights(st, args)
+        return st, handle, w
 
     def finish(self, x, token, args=None):
-        """Phase B: class order (beside the collective), wait for the histogram sum, weights, pooling, heads."""
-        st, handle = token
+        """Phase B: class order (beside the collective), wait for the histogram sum, weights (unless phase A had them),
+        pooling, heads."""
+        st, handle, w_early = token
         ops._mark("begin")                     # (stage timers: this phase may run on another stream than phase A did)
         if isinstance(handle, str):            # "late": the collective starts here, the class ordering runs beside it, and the
             from .dist import allreduce_hist_start      # next batch's phase A (another stream) fills the rest of the wait
@@ -551,7 +560,7 @@ class _CNPredictorBase(nn.Module):
             from .dist import allreduce_hist_finish
             allreduce_hist_finish(handle)
             ops._mark("allreduce_hist")
-        w = self._weights(st, args)
+        w = w_early if w_early is not None else self._weights(st, args)
         xcn1, xcn2, xij = self._pool(st, w, x)
         return self._heads(x, xcn1, xcn2, xij, getattr(st, "cls", None))
 
@@ -930,6 +939,7 @@ class CNLinkPredictorbaselearn(_CNPredictorBase):
     """cn7 (model.py:3021-3229): cn1 column-normalised with ``args.sum`` for columns hit fewer than
     twice, Chebyshev diagonal hard-wired to T0 = identity, raw cn2; same heads."""
     _xcn2_on_union = False
+    _weights_need_args = True
 
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, args, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):

@@ -42,7 +42,7 @@ def score_edges(predictor, h: Tensor, adj, adj2, edges: Tensor, batch_size: int,
 
         def begin(it):
             e = edges[perms[it]].t().contiguous()
-            return predictor.begin(h, adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e), e, slot=it)
+            return predictor.begin(h, adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e), e, slot=it, args=args)
 
         def flow(it):
             if len(done) >= max(run_ahead, 1):
@@ -76,7 +76,7 @@ def score_mrr_split(predictor, h: Tensor, adj, source: Tensor, target: Tensor, t
             def begin(it):
                 e = torch.stack((src_all[perms[it]], dst_all[perms[it]]))
                 cn1, cn2 = get_cn1_cn2(adj, e)
-                return predictor.begin(h, adj, cn1, cn2, e, slot=it)
+                return predictor.begin(h, adj, cn1, cn2, e, slot=it, args=args)
 
             for out in overlapped_steps(begin, lambda tok: predictor.finish(h, tok, args), len(perms), batch=batch_size):
                 outs.append(out.reshape(-1))
