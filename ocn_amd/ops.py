@@ -30,8 +30,10 @@ walk_share_min = 2               # walk route, B <= 4096: candidates sharing a s
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 heavy_first = True               # ... and the pooling (H = 256) visits its slot groups longest first (ocn_cn_flags' gcost -> ocn_gather_schedule)
 overlap_depth = int(os.environ.get("OCN_OVERLAP_DEPTH", 3))   # scratch sets of a predictor = the most batches a scoring loop keeps in flight
-overlap_deep_max_batch = 4096    # ... which it does for batches up to this size (the drivers' 2 048-candidate walk-route batches: two intersection
-                                 # passes beside one pooling + heads; citation2 shape 3.96 -> 4.81 M edges/s); larger batches: two in flight
+overlap_deep_max_batch = int(os.environ.get("OCN_OVERLAP_DEEP_MAX_BATCH", 1 << 30))   # ... which it does for batches up to this size: every size by
+                                 # default.  Two intersection passes beside one pooling + heads pay where phase A is the longer one: the drivers'
+                                 # 2 048-candidate walk-route batches (citation2 shape 3.96 -> 4.81 M edges/s) and ANY trained cn5 model, whose
+                                 # order-exact column sums sit in phase A (collab shape 104 -> 126 M); a fresh model's large batches lose < 1 %
 # Sharded scoring loops: where a batch's histogram all-reduce starts.  None = by the loop: in phase B (on the caller's stream, the
 # class ordering and the NEXT batch's phase A on the other stream fill the wait) when the loop overlaps two streams — started from
 # the side stream the collective cost 25 % of the step in the one-rank rehearsal (105 M against 140 M edges/s) — and in phase A (a
