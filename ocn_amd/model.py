@@ -543,8 +543,11 @@ class _CNPredictorBase(nn.Module):
         # the collab shape — belong to phase A, which the scoring loops run beside the previous batch's pooling and heads.
         # (cn7's weights need ``args.sum``: pass ``args``.)
         w = None
-        if handle is None and not self._sharded and (args is not None or not self._weights_need_args):
-            w = self._weights(st, args)
+        if handle is None and not self._sharded:
+            if args is not None or not self._weights_need_args:
+                w = self._weights(st, args)
+            self._class_order(st, x)               # reads the per-row counts only: off the critical phase too
+            st.prepare_schedule(x.shape[1])        # ... as does the pooling's visiting order (group costs of the intersection pass)
         return st, handle, w
 
     def finish(self, x, token, args=None):
@@ -555,7 +558,8 @@ class _CNPredictorBase(nn.Module):
         if isinstance(handle, str):            # "late": the collective starts here, the class ordering runs beside it, and the
             from .dist import allreduce_hist_start      # next batch's phase A (another stream) fills the rest of the wait
             handle = allreduce_hist_start(st.hist, self._shard_group, valued=True)
-        self._class_order(st, x)
+        if not getattr(st, "_cls_decided", False):
+            self._class_order(st, x)
         if handle is not None:
             from .dist import allreduce_hist_finish
             allreduce_hist_finish(handle)

@@ -431,7 +431,7 @@ def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
 def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights: Tensor, h: Tensor,
               order: Optional[Tensor] = None, max_row_len: int = 0, wsd=None, out_row: Optional[Tensor] = None,
               cnt1: Optional[Tensor] = None, cnt2: Optional[Tensor] = None, rec: Optional[Tensor] = None,
-              sched: Optional[Tensor] = None, rowsum: Optional[Tensor] = None):
+              sched: Optional[Tensor] = None, rowsum: Optional[Tensor] = None, sched_ready: bool = False):
     _req(weights, torch.float32, "weights", 2)
     _req(h, torch.float32, "h", 2)
     if weights.shape[0] != h.shape[0] or weights.shape[1] != 4:
@@ -444,7 +444,8 @@ def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights
     if sched is not None and rec is not None and H == 256 and B % 32 == 0 and B // 32 <= 65535:
         n_groups = B // 4             # the intersection pass left the groups' costs in sched[:n_groups]; their visiting order follows
         perm = sched[n_groups:]
-        check(_lib.lib().ocn_gather_schedule(ptr(sched), n_groups, ptr(perm), stream_ptr()), "ocn_gather_schedule")
+        if not sched_ready:           # (a scoring loop's phase A has run gather_schedule already)
+            check(_lib.lib().ocn_gather_schedule(ptr(sched), n_groups, ptr(perm), stream_ptr()), "ocn_gather_schedule")
     check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags),
                                    ptr(wc), ptr(weights), ptr(h), H, int(max_row_len), ptr(out[0]), ptr(out[1]),
                                    ptr(out[2]), ptr(out_row), ptr(cnt1), ptr(cnt2), ptr(rec), ptr(perm), ptr(rowsum),
@@ -455,6 +456,17 @@ def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights
 
 CLASS_RANGES = 7                 # include/ocn_hip.h: OCN_CLASS_RANGES
 R_CN1, R_BOTH, R_CN2_ONLY, R_ANY, R_NONE, R_CN1_ONLY, R_ALL = range(CLASS_RANGES)
+
+
+@_on_device
+def gather_schedule(sched: Tensor, B: int) -> bool:
+    """The pooling's longest-first visiting order from the group costs the intersection pass left in ``sched[:B // 4]``
+    (ocn_gather_schedule) into ``sched[B // 4:]``; False where the schedule does not apply (cn_gather's own conditions)."""
+    if sched is None or B % 32 != 0 or B // 32 > 65535 or B == 0:
+        return False
+    n_groups = B // 4
+    check(_lib.lib().ocn_gather_schedule(ptr(sched), n_groups, ptr(sched[n_groups:]), stream_ptr()), "ocn_gather_schedule")
+    return True
 
 
 @_on_device

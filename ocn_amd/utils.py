@@ -169,7 +169,12 @@ class CNState:
                              max_row_len=self.adj.max_rowcount(), wsd=self.ws, out_row=out_row,
                              cnt1=self.cnt1, cnt2=self.cnt2, rec=getattr(self, "rec", None) if order is None else None,
                              sched=getattr(self, "sched", None) if order is None else None,
-                             rowsum=None if self.walk else rowsum)
+                             rowsum=None if self.walk else rowsum, sched_ready=getattr(self, "_sched_ready", False))
+
+    def prepare_schedule(self, H: int) -> None:
+        """Phase A of a scoring loop: the pooling's visiting order needs the intersection pass only."""
+        if H == 256 and getattr(self, "sched", None) is not None and getattr(self, "rec", None) is not None:
+            self._sched_ready = ops.gather_schedule(self.sched, self.B)
 
     def gather_backward(self, weights: Tensor, h: Tensor, g1: Tensor, g2: Tensor, g3: Tensor) -> Tensor:
         return ops.cn_gather_backward(self.adj._rowptr, self.adj._col, self.src, self.dst, self.off, self.flags,
