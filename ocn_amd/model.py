@@ -546,8 +546,9 @@ class _CNPredictorBase(nn.Module):
         if handle is None and not self._sharded:
             if args is not None or not self._weights_need_args:
                 w = self._weights(st, args)
-            self._class_order(st, x)               # reads the per-row counts only: off the critical phase too
-            st.prepare_schedule(x.shape[1])        # ... as does the pooling's visiting order (group costs of the intersection pass)
+            if ops.phase_a_extras:
+                self._class_order(st, x)           # reads the per-row counts only: off the critical phase too
+                st.prepare_schedule(x.shape[1])    # ... as does the pooling's visiting order (group costs of the intersection pass)
         return st, handle, w
 
     def finish(self, x, token, args=None):

@@ -40,6 +40,7 @@ overlap_deep_max_batch = int(os.environ.get("OCN_OVERLAP_DEEP_MAX_BATCH", 1 << 3
 # whole step ahead, hidden behind the next intersection pass in stream order) on one stream.  OCN_REDUCE_IN_FINISH=0|1 forces it.
 shard_reduce_in_finish = {"0": False, "1": True}.get(os.environ.get("OCN_REDUCE_IN_FINISH", ""), None)
 _overlap_active = False          # set by pipeline.overlapped_steps while it runs phase A on side streams
+phase_a_extras = os.environ.get("OCN_PHASE_A_EXTRAS", "1") != "0"   # unsharded loops: class ordering + pooling schedule in phase A (else phase B)
 overlap_min_batch = 2048         # ... from this many candidates per batch (Cora-sized batches: the two event hand-offs cost more than the overlap gives)
 overlap_streams = os.environ.get("OCN_ONE_STREAM", "0") != "1"   # scoring loops: phase A of batch t + 1 on a second stream beside phase B of batch t (pipeline.overlapped_steps)
 share_full_rows = True           # cn7 on a dense graph: candidates whose whole source row is cn2 copy (A h)[source] (ocn_cn_gather `rowsum`)
