@@ -325,7 +325,7 @@ def main():
                          "the roofline objects are then null)")
     ap.add_argument("--prewarm", type=int, default=64, help="untimed runtime pre-warm steps before --warmup")
     ap.add_argument("--run-ahead", type=int, default=6, help="steps the host may enqueue ahead of the GPU")
-    ap.add_argument("--timer-every", type=int, default=5, help="record stage events on every n-th timed step")
+    ap.add_argument("--timer-every", type=int, default=16, help="record stage events on every n-th timed step")
     ap.add_argument("--rehearse-collectives", action="store_true",
                     help="one rank, but with the N > 1 code path: RCCL process group, histogram all-reduce and score "
                          "all-gather executed (a one-GPU box can then time what the collectives add); not a bench line")
@@ -501,7 +501,7 @@ def main():
     timer1, dt1 = None, None
     overlapped = pipelined and "HIP stream" in pattern_main
     if overlapped and not args.no_stage_timers:
-        n1 = min(args.steps, 40)
+        n1 = min(args.steps, 64)
         timer1 = StageTimer(pool=40 * (n1 // args.timer_every + 1))
         dt1, _, _ = timed_loop(n1, timer1, overlap=False)
         dt1 /= n1
