@@ -1108,6 +1108,49 @@ def test_two_stream_scoring_loop_equals_one_stream(case, name, monkeypatch):
     assert torch.equal(two, one)
 
 
+def test_phase_a_carries_weights_class_order_and_schedule(hiplib):
+    """The scoring loops' phase A at H = 256 with batches the pooling schedule applies to (multiples of 32, large enough to
+    be processed in source order): begin() leaves column weights, class-major order and the longest-first schedule, finish()
+    only pools and runs the heads — scores equal forward()'s bit for bit, fresh and trained model, with the extras in phase
+    A and (OCN_PHASE_A_EXTRAS=0's path) in phase B."""
+    from ocn_amd import ops
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.pipeline import overlapped_steps
+    from ocn_amd.utils import adjoverlap
+    n, H, B = 6000, 256, 4096
+    oadj = make_graph(n, 14, 500, seed=21)
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    torch.manual_seed(2)
+    x = torch.randn(n, H, device=DEV)
+    pred = predictor_dict["cn5"](H, H, 1, 3, 0.0, 0.0, True).to(DEV).eval()
+    batches = [batch(oadj, B, 40 + q).to(DEV) for q in range(5)]
+
+    def handles(e):
+        return adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e)
+
+    with torch.no_grad():
+        for ip in (0.0, 0.37):
+            pred.innerprod.fill_(ip)
+            ref = [pred(x, adj, *handles(e), e).clone() for e in batches]
+            for extras in (True, False):
+                ops.phase_a_extras = extras
+                try:
+                    seen = []
+
+                    def begin(it):
+                        tok = pred.begin(x, adj, *handles(batches[it]), batches[it], slot=it)
+                        seen.append((tok[2] is not None, getattr(tok[0], "_cls_decided", False), getattr(tok[0], "_sched_ready", False)))
+                        return tok
+                    outs = [o.clone() for o in overlapped_steps(begin, lambda tok: pred.finish(x, tok), len(batches), batch=B)]
+                finally:
+                    ops.phase_a_extras = True
+                torch.cuda.synchronize()
+                assert all(w for w, _, _ in seen) and all(c == extras and s == extras for _, c, s in seen), seen
+                for a, b in zip(outs, ref):
+                    assert torch.equal(a, b)
+
+
 def test_order_sensitive_column_sum_known_answer_on_the_gpu(hiplib):
     """tests/golden/order_sensitive_colsum.json (hand-derived): five entries in one column whose fp32 sum is 2^25 only in
     ascending batch-row order (2^25 + 4 with the small entries first, or with one rounding of the exact sum)."""
