@@ -171,10 +171,14 @@ int ocn_wgrad(const float* dY, int64_t ldY, const float* X, int64_t ldX, int64_t
   if (B < 0 || N <= 0 || K <= 0 || !dW || !workspace || ldY < N || ldX < K) return OCN_EINVAL;
   if (B > 0 && (!dY || !X)) return OCN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  if (B == 0) {
-    hipError_t e = hipMemsetAsync(dW, 0, (size_t)N * K * 4, st);
-    if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)N * 4, st);
-    return (int)e;
+  if (B == 0) {                                // an empty batch: zeros, from the reduce kernel over no slices (the library issues no memset)
+    const int64_t nk0 = (int64_t)N * K;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((nk0 + OCN_BLOCK - 1) / OCN_BLOCK, 4096)), dim3(OCN_BLOCK), 0, st,
+                       (const float*)workspace, 0, (i64)nk0, dW);
+    if (db)
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 64)), dim3(OCN_BLOCK), 0, st,
+                         (const float*)workspace, 0, (i64)N, db);
+    return launch_status();
   }
   int tn, tk, S; int64_t R;
   wgrad_plan(B, N, K, tn, tk, S, R);
