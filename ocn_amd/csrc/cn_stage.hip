@@ -1108,6 +1108,16 @@ __device__ __forceinline__ void long_store(const f32x4 (&x)[RPG][NV], float4* __
 #define LONG_SMALL_THREADS 1024             /* hub-row workgroup of a small batch (B <= 4096); 512 (two per CU) measured 5 % slower */
 #endif
 #define LONG_SLAB_BYTES(threads) ((threads) >= 512 ? 32768 : 16384)   /* per half; dynamic LDS = two halves */
+#ifdef OCN_X_LONG_STAMPS   /* diagnostic build: where a hub row's time goes (wave 0 of every hub-row workgroup; tools/longstamps.py) */
+__device__ unsigned long long g_long_stamps[8];
+extern "C" int ocn_debug_long_stamps(unsigned long long* out, int reset) {
+  if (reset) { static unsigned long long z[8]; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_long_stamps), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_long_stamps), sizeof(unsigned long long) * 8);
+}
+#define LSTAMP(k) do { if (threadIdx.x == 0) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long tn = __builtin_amdgcn_s_memtime(); lt[k] += tn - lprev; lprev = tn; } } while (0)
+#else
+#define LSTAMP(k) do {} while (0)
+#endif
 template <int LPE, int NV, int LONG_THREADS>
 __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
@@ -1143,13 +1153,18 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
   float acc1[FPL], acc2[FPL];
 #pragma unroll
   for (int q = 0; q < FPL; ++q) acc1[q] = acc2[q] = 0.f;
+#ifdef OCN_X_LONG_STAMPS
+  unsigned long long lt[6] = {0, 0, 0, 0, 0, 0}, lprev = __builtin_amdgcn_s_memtime();
+#endif
   for (i64 p0 = 0; p0 < da; p0 += LONG_THREADS) {
     const i64 p = p0 + threadIdx.x;
     int32_t k = 0, cv = 1;
     unsigned f = 0;
     if (p < da) { k = colA[a0 + p]; f = flags[base + p]; if (wc) cv = wc[base + p]; }
+    LSTAMP(0);                                                   // ids / flags / cn2 values
     float wa = 0.f, wb = 0.f;
     if (f) entry_weights(f, weights[k], (float)cv, wa, wb);
+    LSTAMP(1);                                                   // column weights
     const bool need = (wa != 0.f) | (wb != 0.f);
     const unsigned long long m = __ballot(need);
     if (lane == 0) s_wcnt[wv] = __popcll(m);
@@ -1168,6 +1183,7 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
     }
     __syncthreads();
     const int nsr = (n + SLAB - 1) / SLAB;
+    LSTAMP(2);                                                   // compaction (two barriers)
     // Sub-round u lives in register set u & 1 of the fetching waves from its request until it is stored two steps
     // later.  Step t: waves 1.. store sub-round t + 1 and request t + 3 into the set it leaves; wave 0 sums sub-round t
     // from the slab half t & 1; barrier.
@@ -1199,7 +1215,18 @@ __global__ __launch_bounds__(LONG_THREADS) void cn_gather_long_kernel(
         __syncthreads();
       }
     }
+    LSTAMP(3);                                                   // the round's sub-rounds: fetch / store / sum, a barrier each
+#ifdef OCN_X_LONG_STAMPS
+    if (threadIdx.x == 0) { lt[4] += (unsigned long long)n; lt[5] += 1; }
+#endif
   }
+#ifdef OCN_X_LONG_STAMPS
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < 6; ++q) atomicAdd(&g_long_stamps[q], lt[q]);
+    atomicAdd(&g_long_stamps[6], 1ull);
+    atomicMax(&g_long_stamps[7], lt[0] + lt[1] + lt[2] + lt[3]);
+  }
+#endif
   if (wv == 0 && lane < AL) {
     const i64 o = (out_row ? out_row[e] : e) * H + lane * FPL;
 #pragma unroll
