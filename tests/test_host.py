@@ -227,3 +227,29 @@ def test_heads_kernel_isa_audit():
     problems, stats = mod.audit(mod.compile_asm())
     assert len(stats) == 4 and all(s["mfma"] > 0 and s["ds_read"] > 0 for s in stats.values())      # H in {128, 256} x LayerNorm on / off
     assert not problems, problems[:5]
+
+
+def test_training_and_sort_kernels_do_not_spill(tmp_path):
+    """The round-3 kernels of the training loop (COO -> CSR build with its row sorts, weight gradient, deterministic pooling
+    backward): compiled for gfx950, none keeps a register in scratch and the weight-gradient kernel holds its MFMAs."""
+    import os
+    import re
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), "..")
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    seen = {}
+    for name in ("coo_csr", "wgrad", "pool_bwd"):
+        out = tmp_path / (name + ".s")
+        subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S",
+                        "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "ocn_amd", "csrc"),
+                        os.path.join(root, "ocn_amd", "csrc", name + ".hip"), "-o", str(out)], check=True, capture_output=True)
+        text = out.read_text()
+        for m in re.finditer(r"\.name:\s+(\S+)(.*?)\.vgpr_spill_count:\s+(\d+)", text, re.S):
+            kernel, body, spills = m.group(1), m.group(2), int(m.group(3))
+            if ".private_segment_fixed_size" in body:
+                scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", body).group(1))
+                seen[kernel] = (spills, scratch)
+        if name == "wgrad":
+            assert text.count("v_mfma_f32_32x32x16_bf16") >= 24            # four tiles x six cross terms
+    assert len(seen) >= 10, sorted(seen)
+    assert all(v == (0, 0) for v in seen.values()), {k: v for k, v in seen.items() if v != (0, 0)}
