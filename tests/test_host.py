@@ -253,3 +253,28 @@ def test_training_and_sort_kernels_do_not_spill(tmp_path):
             assert text.count("v_mfma_f32_32x32x16_bf16") >= 24            # four tiles x six cross terms
     assert len(seen) >= 10, sorted(seen)
     assert all(v == (0, 0) for v in seen.values()), {k: v for k, v in seen.items() if v != (0, 0)}
+
+
+def test_overlapped_steps_host_order_without_a_gpu():
+    """pipeline.overlapped_steps on one stream (no HIP here): phase A of batch t + 1 is enqueued before phase B of batch t,
+    results come back in batch order, the hooks bracket every step, and no scratch set is begun again before the batch
+    that used it has finished."""
+    from ocn_amd.pipeline import overlapped_steps
+    log = []
+
+    def begin(it):
+        log.append(("A", it))
+        return it
+
+    def finish(tok):
+        log.append(("B", tok))
+        return tok * 10
+
+    outs = list(overlapped_steps(begin, finish, 5, before_step=lambda it: log.append(("pre", it)),
+                                 after_step=lambda it: log.append(("post", it)), overlap=False))
+    assert outs == [0, 10, 20, 30, 40]
+    order = [e for e in log if e[0] in "AB"]
+    assert order == [("A", 0), ("A", 1), ("B", 0), ("A", 2), ("B", 1), ("A", 3), ("B", 2), ("A", 4), ("B", 3), ("B", 4)]
+    for it in range(5):
+        assert log.index(("pre", it)) < log.index(("B", it)) < log.index(("post", it))
+    assert list(overlapped_steps(begin, finish, 0, overlap=False)) == []
