@@ -28,7 +28,9 @@ extern "C" {
 /* ABI history — 2: workspaces zero on entry / left zero, ocn_check_edges, ocn_zero_regions, ocn_cn_colsum_exact, walk prep /
  * group entries, dense block route, ocn_heads_fused; 3: ocn_cn_flags takes bit rows of T1, ocn_bitrows_from_csr;
  * 4: ocn_batch_prep, ocn_order_by_node_finish; 5: slot records (`rec`) from ocn_cn_flags to ocn_cn_gather;
- * 6: ocn_heads_fused on f16 hi/lo panels (ocn_heads_split_weight replaces ocn_linear_split_weight_chained). */
+ * 6: ocn_heads_fused on f16 hi/lo panels (ocn_heads_split_weight replaces ocn_linear_split_weight_chained).
+ * 7: + ocn_coo_to_csr, ocn_wgrad, ocn_cn_gather_backward_det, ocn_gather_schedule; ocn_cn_flags gains `gcost`,
+ *    ocn_cn_gather gains `perm` and `rowsum`. */
 #define OCN_ABI_VERSION 7
 #define OCN_EINVAL (-1)   /* null pointer / negative size / unsupported combination */
 #define OCN_ECAP   (-2)   /* reported through the device status word: flags capacity too small */
