@@ -73,33 +73,51 @@ def head_layout(pred) -> str:
 
 
 class StageTimer:
-    """HIP events on torch's current stream — the stream every ocn_* kernel is launched on."""
+    """HIP events on the stream each ocn_* kernel is launched on.  ``mark(name)`` records an event on torch's CURRENT stream
+    and remembers which stream that was; a stage's duration is the distance between two consecutive marks OF THE SAME
+    STREAM — the scoring loop runs phase A (prep, intersection, weights, class order) on side streams and phase B (pooling,
+    heads) on the caller's, and an interval that starts at one stream's event and ends at another's measures nothing
+    (VERDICT r3 #4).  Every phase opens with a "begin" mark on its own stream, so a stage interval never spans two phases."""
 
     def __init__(self, pool=0):
         self.events = []
         self.active = True
         self.flops = {}
+        self.sampled_steps = 0
         # hipEventCreate is the expensive part on a busy host: create the events before the timed
         # region, only record() inside it
         self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(pool)]
         for ev in self.pool:                   # torch creates the hipEvent lazily, at the first record()
             ev.record()
+        self._raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
     def mark(self, name, flops=0.0):
         if not self.active:
             return
         self.flops[name] = self.flops.get(name, 0.0) + flops
         ev = self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
+        sid = self._raw(torch._C._cuda_getDevice()) if self._raw else torch.cuda.current_stream().cuda_stream
         ev.record()
-        self.events.append((name, ev))
+        self.events.append((name, ev, sid))
 
     def totals(self):
-        tot, prev = {}, None
-        for name, ev in self.events:
-            if name != "begin" and prev is not None:
-                tot.setdefault(name, []).append(prev.elapsed_time(ev))
-            prev = ev
-        return {k: (sum(v) / len(v), len(v)) for k, v in tot.items()}
+        """{stage: (mean ms per launch, launches, ms per sampled step)} from same-stream pairs only."""
+        tot, prev = {}, {}
+        for name, ev, sid in self.events:
+            p = prev.get(sid)
+            if name != "begin" and p is not None:
+                tot.setdefault(name, []).append(p.elapsed_time(ev))
+            prev[sid] = ev
+        n = max(self.sampled_steps, 1)
+        return {k: (sum(v) / len(v), len(v), sum(v) / n) for k, v in tot.items()}
+
+
+def sampled_step(it, steps):
+    """Stage events are recorded on at least 8 steps of the timed region whatever --steps is (every max(1, steps // 8)-th),
+    never on step 0: with three batches in flight step 0 PRIMES the pipeline (three phase-A passes are enqueued before its
+    phase B), every later step enqueues exactly one phase A (of batch it + 2) and one phase B (of batch it)."""
+    every = max(1, steps // 8)
+    return it > 0 and it % every == (every - 1 if every > 1 else 0)
 
 
 def make_predictor(cfg, dev):
@@ -325,7 +343,8 @@ def main():
                          "the roofline objects are then null)")
     ap.add_argument("--prewarm", type=int, default=64, help="untimed runtime pre-warm steps before --warmup")
     ap.add_argument("--run-ahead", type=int, default=6, help="steps the host may enqueue ahead of the GPU")
-    ap.add_argument("--timer-every", type=int, default=16, help="record stage events on every n-th timed step")
+    ap.add_argument("--timer-every", type=int, default=0, help="record stage events on every n-th timed step (0 = steps // 8: at least 8 sampled steps)")
+    ap.add_argument("--repeats", type=int, default=3, help="times the timed loop runs in all; `value` is the first run, the others are reported beside it")
     ap.add_argument("--rehearse-collectives", action="store_true",
                     help="one rank, but with the N > 1 code path: RCCL process group, histogram all-reduce and score "
                          "all-gather executed (a one-GPU box can then time what the collectives add); not a bench line")
@@ -450,8 +469,9 @@ def main():
             tw = time.perf_counter()
             ring[it % run_ahead].synchronize()
             t_waits[0] += time.perf_counter() - tw
-            if timer:                                  # stage events on every `timer_every`-th step only: on a busy
-                timer.active = it % args.timer_every == 0   # host each hipEventRecord costs tens of microseconds
+            if timer:                                  # stage events on >= 8 steps of the region, never on the priming step
+                timer.active = sampled_step(it, steps) if not args.timer_every else (it > 0 and it % args.timer_every == 0)
+                timer.sampled_steps += int(timer.active)
                 timer.mark("begin")
 
         def after_step(it):
@@ -492,9 +512,12 @@ def main():
             dt = tmax.item()
         return dt, t_launch, out
 
-    timer = None if args.no_stage_timers else StageTimer(pool=40 * (args.steps // args.timer_every + 1))
+    timer = None if args.no_stage_timers else StageTimer(pool=48 * (args.steps // max(args.timer_every or max(1, args.steps // 8), 1) + 2))
     dt, t_launch, out = timed_loop(args.steps, timer)
     pattern_main = pattern[0]
+    # the same timed loop again (no stage events): the spread of the step time from run to run, reported beside `value`
+    runs = [dt / args.steps] + [timed_loop(args.steps, None)[0] / args.steps for _ in range(max(args.repeats, 1) - 1)]
+    pattern[0] = pattern_main
     # The same loop on ONE stream (untimed for `value`): per-kernel durations without the other stream's kernels beside
     # them — under the two-stream overlap a launch's duration includes what it yields to its neighbour — and the step time
     # the overlap is measured against.  Reported next to the timed region's own figures, never instead of them.
@@ -502,7 +525,7 @@ def main():
     overlapped = pipelined and "HIP stream" in pattern_main
     if overlapped and not args.no_stage_timers:
         n1 = min(args.steps, 64)
-        timer1 = StageTimer(pool=40 * (n1 // args.timer_every + 1))
+        timer1 = StageTimer(pool=48 * (n1 // max(args.timer_every or max(1, n1 // 8), 1) + 2))
         dt1, _, _ = timed_loop(n1, timer1, overlap=False)
         dt1 /= n1
         pattern[0] = pattern_main
@@ -535,11 +558,10 @@ def main():
     if rank == 0:
         per = [batch_bytes(wl, m, H) for m in mines]
         ab = {k: sum(p[k] for p in per) / NB for k in per[0]}
-        stages = {k: dict(ms=v[0], launches=v[1]) for k, v in (timer.totals() if timer else {}).items()}
-        sampled = len([1 for it in range(args.steps) if it % args.timer_every == 0])
+        stages = {k: dict(ms=v[0], launches=v[1], ms_per_step=v[2]) for k, v in (timer.totals() if timer else {}).items()}
+        sampled = max(timer.sampled_steps, 1) if timer else 1
         roof, roof_hbm, roofs = None, None, {}
         if stages:
-            per_step = {k: v["ms"] * v["launches"] / sampled for k, v in stages.items()}
             kname = {"cn_flags": "cn_walk_kernel" if cfg["route"] == "walk" else "cn_flags_kernel",
                      "cn_gather": "cn_gather_wave_kernel" if (H <= 64 and mines[0].shape[1] * (H // 4) < 262144) else "cn_gather_kernel"}
             for k, comp, form in (("cn_flags", "flags_compulsory", "flags_formula"), ("cn_gather", "gather_compulsory", "gather_formula")):
@@ -558,10 +580,9 @@ def main():
                                      "shared rows are served by L2; traffic = PMC 2*FETCH_SIZE + WRITE_SIZE of the "
                                      "committed profile")
                 stages[k]["compulsory_GBps"] = roofs[k]["achieved"]
-            stages1 = {k: dict(ms=v[0], launches=v[1]) for k, v in (timer1.totals() if timer1 else {}).items()}
-            # the dominant kernel: by its time per step on one stream (under overlap the two streams' durations are not additive)
-            base = stages1 if stages1 else stages
-            dom = max((k for k in ("cn_flags", "cn_gather", "linear") if k in base), key=lambda k: base[k]["ms"] * base[k]["launches"])
+            stages1 = {k: dict(ms=v[0], launches=v[1], ms_per_step=v[2]) for k, v in (timer1.totals() if timer1 else {}).items()}
+            # the dominant kernel: the stage with the most time per STEP inside the timed region (same-stream event pairs)
+            dom = max((k for k in ("cn_flags", "cn_gather", "linear") if k in stages), key=lambda k: stages[k]["ms_per_step"])
             roof_hbm = roofs.get("cn_gather")
             if "linear" in stages:
                 # MFMA work of the MLP heads per launch.  The fused kernel (ocn_heads_fused, H >= 128) multiplies a row by
@@ -631,6 +652,15 @@ def main():
             "value": B_total * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_detail": ("sparse stage (intersection, column weights, pooling): f32 products and sums rounded separately, "
+                             "integer counts exact; MLP heads: "
+                             + ("f16x3-split, f32 accumulate (each f32 product = three f16 MFMAs on hi/lo splits of both operands; the "
+                                "dropped lo*lo term is below 2^-22 relative)" if H >= ops.fused_heads_min_width and ops.fused_heads
+                                else "bf16x6-split, f32 accumulate (each f32 product = six bf16 MFMAs)")),
+            "value_runs": [B_total / r for r in runs], "value_min": B_total / max(runs),
+            "value_median": B_total / sorted(runs)[len(runs) // 2], "ms_per_step_runs": [r * 1e3 for r in runs],
+            "stage_timer": {"sampled_steps": sampled, "rule": "HIP events on the launch stream, same-stream pairs only, "
+                            ">= 8 sampled steps, never the priming step"},
             "config": {"workload": f"ogbl-{args.dataset}-shaped synthetic graph, {cfg['enc']} {cfg['conv']} x{cfg['layers']} "
                                    f"hiddim={H} predictor={cfg['pred']} built as the reference drivers build it (only cndeg "
                                    f"forwarded: tailact=False, use_xlin=False, beta=1, lnnn={cfg['lnnn']}; head = "

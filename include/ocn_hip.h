@@ -30,10 +30,20 @@ extern "C" {
  * 4: ocn_batch_prep, ocn_order_by_node_finish; 5: slot records (`rec`) from ocn_cn_flags to ocn_cn_gather;
  * 6: ocn_heads_fused on f16 hi/lo panels (ocn_heads_split_weight replaces ocn_linear_split_weight_chained).
  * 7: + ocn_coo_to_csr, ocn_wgrad, ocn_cn_gather_backward_det, ocn_gather_schedule; ocn_cn_flags gains `gcost`,
- *    ocn_cn_gather gains `perm` and `rowsum`. */
-#define OCN_ABI_VERSION 7
+ *    ocn_cn_gather gains `perm` and `rowsum`.
+ * 8: a scan whose workspace was not zero ends in OCN_SCAN_POISON totals and a status bit instead of a GPU trap; `status` is
+ *    int32[4] for every intersection entry, word 3 the sticky error word. */
+#define OCN_ABI_VERSION 8
 #define OCN_EINVAL (-1)   /* null pointer / negative size / unsupported combination */
 #define OCN_ECAP   (-2)   /* reported through the device status word: flags capacity too small */
+
+/* Device status words of a candidate batch: int32[4].  [0] = error bits of THIS batch (cleared by the caller / by
+ * ocn_batch_prep's resets with the batch's other scratch), [1], [2] = work-item tickets of the walk route, [3] = the same
+ * error bits, STICKY: the library only ever ORs into it; the caller clears it when it has read it, so a scoring loop can
+ * check a whole split with one read (ocn_amd.pipeline does) instead of one host sync per batch. */
+#define OCN_ST_CAP  1     /* off[B] > flags_cap: the flag buffer is too small (nothing is written past the cap) */
+#define OCN_ST_SCAN 2     /* the batch's offsets come from a scan that gave up (OCN_SCAN_POISON): its workspace was not zero */
+#define OCN_SCAN_POISON (-1)   /* out[n] of a scan entry whose workspace was not zero on entry (see ocn_scan_workspace_bytes) */
 
 /* bits of a CN flag byte */
 #define OCN_F_CN1 1u      /* neighbour k of src is in adj1-target row of dst  (cn1 entry) */
@@ -44,8 +54,13 @@ int ocn_abi_version(void);
 /* Scratch bytes the scan entries need for `n` items.  The workspace must be ZERO when first handed to the library
  * (the caller zeroes it once, when it allocates it); every entry leaves it zero again, so it can be reused from call
  * to call — inputs beyond one tile are scanned by a single launch whose tiles chain through this state.  A workspace
- * that is NOT zero breaks the chain: the launch then ends in a GPU trap (the process aborts) after a bounded wait —
- * never in a hang, and never in prefix sums that are silently wrong. */
+ * that is NOT zero breaks the chain (two launches in flight on one workspace, a buffer never cleared).  The launch then
+ * neither hangs nor traps: after a bounded wait the tiles that cannot be chained write ZERO offsets for their items and
+ * the total out[n] becomes OCN_SCAN_POISON (< 0).  Consumers test the total and do not trust the offsets: ocn_cn_flags /
+ * ocn_cn_walk_flags raise OCN_ST_SCAN in their status words and treat the batch as empty (zero counts, empty slot
+ * records), ocn_order_by_node_finish / ocn_class_order fall back to batch order (a correct order, only slower), and a
+ * caller that reads a total on the host (nnz of a product, the flag capacity) sees a negative number.  Detection is
+ * best effort: the contract (ZERO on entry, one launch at a time per workspace) stays the caller's. */
 int64_t ocn_scan_workspace_bytes(int64_t n);
 
 /* Zero up to 8 device arrays (4-byte aligned, byte counts multiples of 4) with one launch: the per-batch reset of
@@ -123,7 +138,8 @@ int ocn_scan_i32(const int32_t* in, int64_t n, int64_t* out, void* workspace, vo
  * gcost (or NULL): int32[ceil(B / 4)]: per group of four consecutive processing slots the number of cn1 + cn2 entries
  * its candidates have — what the group will cost the pooling; see ocn_gather_schedule.
  * bitmapT1: the same for T1 (ocn_bitrows_from_csr; small dense graphs); rowptrT1 / colT1 may then be NULL.
- * status: device int32, bit 0 set if off[B] > flags_cap (nothing is written past the cap).
+ * status: device int32[4] (above): OCN_ST_CAP if off[B] > flags_cap (nothing is written past the cap), OCN_ST_SCAN if
+ * off[B] is OCN_SCAN_POISON; both also ORed into the sticky word status[3].
  * order (here and below): optional permutation of 0..B-1 giving the order in which the batch rows
  * are PROCESSED (e.g. sorted by src so that rows sharing neighbourhoods meet in L2); every output
  * stays indexed by the batch row.  NULL = batch order. */
@@ -143,8 +159,8 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA,
  * additionally accumulates walks = sum of the counts of column k; cnt2[e] = number of non-zero
  * entries of cn2 row e.  Work is cut into items of ocn_walk_chunk() neighbours of i (chunk_off from
  * ocn_chunk_offsets), so hub source nodes spread over many workgroups; cnt1 / cnt2 must be ZERO on
- * entry (a row's items add into them).  `status` is int32[4] here, ZERO on entry: [0] receives the
- * overflow flag as for ocn_cn_flags, [1] and [2] are the work-item ticket counters of the two sweeps. */
+ * entry (a row's items add into them).  `status`: words [0] .. [2] ZERO on entry: [0] receives the
+ * error bits as for ocn_cn_flags, [1] and [2] are the work-item ticket counters of the two sweeps, [3] the sticky word. */
 int32_t ocn_walk_chunk(void);
 int ocn_cn_walk_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* nds /* or NULL */,
                       const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
@@ -173,7 +189,7 @@ int ocn_walk_rev_offsets(const int64_t* rowptrA, const int64_t* nds, const int64
  * to the shared sweep ocn_cn_walk_group if their targets' rows sum to at most 4096 entries — if at least `min_share`
  * of them do (g_active[slot]; g_item_off = exclusive scan of the group's work items, one per meta[2] x 64 neighbours of the
  * source) —, every other candidate keeps its per-candidate work items in chunk_off / rev_off (as ocn_chunk_offsets /
- * ocn_walk_rev_offsets; 0 for the candidates of the shared sweep); cnt1, cnt2, status[4], scal[4] are cleared.  meta: int32[4] ([1] = the shared sweep's ticket).  rev_off NULL iff nds is.
+ * ocn_walk_rev_offsets; 0 for the candidates of the shared sweep); cnt1, cnt2, status[0..2], scal[4] are cleared.  meta: int32[4] ([1] = the shared sweep's ticket).  rev_off NULL iff nds is.
  *
  * ocn_cn_walk_group: the rows N(k), k in N(i), that a candidate (i, j) sweeps for cn2[e,k] = |N(k) n N(j)| are the same
  * for every candidate with source i (the MRR layout scores 1000 negatives per source, NeighborOverlapCitation2.py:
@@ -302,6 +318,15 @@ int ocn_cn_gather_backward_det(const int64_t* rowptrA, const int32_t* colA, cons
                                int64_t B, const int64_t* off, const uint8_t* flags, const int32_t* wc, int64_t flags_cap,
                                const float* weights, const float* h, int64_t N, int32_t H, const float* g1,
                                const float* g2, const float* g3, float* dh, void* workspace, void* stream);
+/* The first half of ocn_cn_gather_backward_det alone — the per-node key lists (count, scan, fill, per-list sort) — for
+ * inspection: tests check the lists against a host-side reference BEFORE the accumulate pass forms addresses from them.
+ * workspace as above; afterwards col_off = int64[N + 1] at its start, keys = int32[col_off[N]] at
+ * ocn_cn_gather_backward_det_keys_offset(N) bytes: a key < flags_cap is the flag position of a CN entry of that node, a key
+ * flags_cap + 2 e + s is candidate e's Hadamard term at its source (s = 0) or target (s = 1). */
+int64_t ocn_cn_gather_backward_det_keys_offset(int64_t N);
+int ocn_cn_gather_backward_det_lists(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
+                                     int64_t B, const int64_t* off, const uint8_t* flags, int64_t flags_cap, int64_t N,
+                                     void* workspace, void* stream);
 
 /* CSR SpMM of the encoders: torch_sparse spmm_add/mean/max (model.py:42-55), PyG GCNConv
  * propagate (model.py:58-68), pygho/torch COO @ dense (model.py:105-113).

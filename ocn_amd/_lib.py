@@ -19,7 +19,7 @@ INCLUDE = os.path.join(_ROOT, "include")
 
 # name -> (restype, argtypes); must list every symbol include/ocn_hip.h declares
 _P = c_void_p
-ABI_VERSION = 7
+ABI_VERSION = 8
 SIGNATURES = {
     "ocn_abi_version": (c_int32, []),
     "ocn_scan_workspace_bytes": (c_int64, [c_int64]),
@@ -61,6 +61,8 @@ SIGNATURES = {
     "ocn_cn_gather_backward_det_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "ocn_cn_gather_backward_det": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, c_int64, c_int32, _P, _P, _P, _P,
                                              _P, _P]),
+    "ocn_cn_gather_backward_det_keys_offset": (c_int64, [c_int64]),
+    "ocn_cn_gather_backward_det_lists": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, c_int64, c_int64, _P, _P]),
     "ocn_spmm_csr": (c_int32, [_P, _P, _P, c_int64, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "ocn_deg_rsqrt": (c_int32, [_P, _P, c_int64, c_float, _P, _P]),
     "ocn_spgemm_max_cols": (c_int64, []),
@@ -114,22 +116,47 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
-    """Compile csrc/*.hip -> ocn_amd/libocn_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+def build_flags(extra_flags=()):
+    """The compile flags of the product build (tests/test_host.py asserts that no experiment macro is among them)."""
+    return ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17",
+            # the reference's CPU kernels round the product and the sum separately; HIP's __fmul_rn /
+            # __fadd_rn are plain * and + and would be contracted into FMAs under the default mode
+            "-ffp-contract=off",
+            f"-I{INCLUDE}", f"-I{CSRC}", *extra_flags]
+
+
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None, jobs: int = None) -> str:
+    """Compile csrc/*.hip -> ocn_amd/libocn_hip.so for gfx950 (hipcc cross-compiles without a GPU): one object per
+    translation unit under csrc/_build/<flag hash>/ (rebuilt only when the unit, a header or the flags changed), compiled in
+    parallel, then one link."""
+    import hashlib
+    from concurrent.futures import ThreadPoolExecutor
     out = out or LIB_PATH
-    deps = sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INCLUDE, "ocn_hip.h"), os.path.abspath(__file__)]
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(INCLUDE, "ocn_hip.h")]
+    deps = sources() + hdrs + [os.path.abspath(__file__)]
     if not force and not extra_flags and os.path.exists(out) and \
             os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
         return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-std=c++17",
-           # the reference's CPU kernels round the product and the sum separately; HIP's __fmul_rn /
-           # __fadd_rn are plain * and + and would be contracted into FMAs under the default mode
-           "-ffp-contract=off",
-           f"-I{INCLUDE}", f"-I{CSRC}", *extra_flags, "-o", out, *sources()]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    flags = build_flags(extra_flags)
+    tag = hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
+    bdir = os.path.join(CSRC, "_build", tag)
+    os.makedirs(bdir, exist_ok=True)
+    hdr_time = max(os.path.getmtime(h) for h in hdrs)
+    todo, objs = [], []
+    for src in sources():
+        obj = os.path.join(bdir, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            todo.append([hipcc, *flags, "-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    with ThreadPoolExecutor(max_workers=jobs or min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(run, todo))
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs])
     return out
 
 

@@ -80,7 +80,9 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
   __shared__ int32_t s_t2[GPB][OCN_WAVE];
   extern __shared__ __attribute__((aligned(16))) u64 s_hist[];      // LH only: n_cols words
   const int gl = threadIdx.x % G, g = threadIdx.x / G;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && off[B] > cap) atomicOr(status, 1);
+  if (blockIdx.x == 0 && threadIdx.x == 0) status_raise(status, off[B], cap);
+  const bool void_batch = off[B] < 0;        // the offsets come from a scan that gave up (ocn_hip.h: OCN_SCAN_POISON): the batch is treated as
+                                             // empty — zero counts, empty slot records — so that nothing behind this pass indexes with them
   if (LH) {
     for (i64 c = threadIdx.x; c < n_cols; c += OCN_BLOCK) s_hist[c] = 0ull;
     __syncthreads();
@@ -103,6 +105,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_flags_kernel(
                                                                                   // needs no probe at all; on large graphs the two loads would only lengthen the chain)
       }
       base = off[e];
+      if (void_batch) { da = 0; db = 0; dc = 0; base = 0; }
     }
     // stage the short target row, and a 64-point sample of the long one, in this group's LDS slice
     const bool t1_lds = db <= T1_CAP;
@@ -458,7 +461,10 @@ __global__ __launch_bounds__(WALK_THREADS) void cn_walk_kernel(
   WALK_SHARED;
   __shared__ int s_walks[WALK_ROWS];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (blockIdx.x == 0 && threadIdx.x == 0 && off[B] > cap) atomicOr(status, 1);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    status_raise(status, off[B], cap);
+    if (chunk_off[B] < 0) status_raise(status, chunk_off[B], cap);
+  }
   const i64 n_items = chunk_off[B];
 #ifdef OCN_X_WALK_STAMPS   /* diagnostic build: where an item's time goes (tools/walkstamps.py) */
   unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();

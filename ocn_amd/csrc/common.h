@@ -31,6 +31,13 @@ __device__ __forceinline__ float cn5_nip(int sc, float ip) {
 
 static inline int launch_status() { return (int)hipGetLastError(); }
 
+// status words of a candidate batch (ocn_hip.h): [0] = this batch's error bits, [3] = the same bits, sticky — the library
+// only ever ORs into it, the caller clears it when it has read it (a scoring loop reads it once per split, not per batch)
+__device__ __forceinline__ void status_raise(int32_t* status, i64 total, i64 cap) {
+  const int bits = total < 0 ? OCN_ST_SCAN : (total > cap ? OCN_ST_CAP : 0);
+  if (bits) { atomicOr(status, bits); atomicOr(status + 3, bits); }
+}
+
 static inline int grid_for(i64 items_per_block_units, i64 cap = (1 << 20)) {
   i64 g = items_per_block_units < 1 ? 1 : items_per_block_units;
   return (int)(g > cap ? cap : g);

@@ -82,6 +82,10 @@ __global__ __launch_bounds__(OCN_BLOCK) void pb_accumulate_kernel(
         int md[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
+          // The look-ahead loads below are issued for all UNR terms, also past the round's end (only their ADDS are skipped):
+          // their row indices must come from a lane that decoded a key in THIS round.  A lane >= m decodes nothing; round 3's
+          // first form read such lanes here and formed g2 + (a stale endpoint term's NODE id) * H — a row index up to N - 1
+          // into a [B, H] buffer: the GPU memory fault of DESIGN.md §6.  Hence the clamp (and the zero-initialised state above).
           const int r = r0 + u < m ? r0 + u : m - 1;
           const int ea = __builtin_amdgcn_readlane(ra, r), eb = __builtin_amdgcn_readlane(rb, r);
           md[u] = __builtin_amdgcn_readlane(mode, r);        // (a round's tail re-reads its last term's rows: valid addresses)
@@ -136,6 +140,55 @@ int64_t ocn_cn_gather_backward_det_workspace_bytes(int64_t N, int64_t B, int64_t
   return pb_align((N + 1) * 8) + 2 * pb_align(N * 4) + 16 + pb_align(ocn_scan_workspace_bytes(N)) + pb_align((flags_cap + 2 * B) * 4) + 64;
 }
 
+// workspace layout (ocn_cn_gather_backward_det_workspace_bytes)
+struct PbLayout { i64* col_off; int32_t* cursor; int32_t* long_list; int32_t* tickets; void* scan_ws; int32_t* keys; int64_t sw; };
+static PbLayout pb_layout(void* workspace, int64_t N) {
+  char* ws = (char*)workspace;
+  const int64_t a = pb_align((N + 1) * 8), b = pb_align(N * 4), sw = pb_align(ocn_scan_workspace_bytes(N));
+  return PbLayout{(i64*)ws, (int32_t*)(ws + a), (int32_t*)(ws + a + b), (int32_t*)(ws + a + 2 * b), (void*)(ws + a + 2 * b + 16),
+                  (int32_t*)(ws + a + 2 * b + 16 + sw), sw};
+}
+
+// The per-node key lists alone: count -> chained scan -> fill -> per-list sort.  col_off = workspace (int64[N + 1]); the keys
+// sit at ocn_cn_gather_backward_det_keys_offset(N) bytes.
+static int pb_build_lists(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst, int64_t B,
+                          const int64_t* off, const uint8_t* flags, int64_t flags_cap, int64_t N, void* workspace, hipStream_t st) {
+  const PbLayout L = pb_layout(workspace, N);
+  const int gridN = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
+  const int gridB = grid_for((B + OCN_WPB - 1) / OCN_WPB, 1 << 16);
+  const int gridW = grid_for((N + OCN_WPB - 1) / OCN_WPB, 1 << 15);
+  hipLaunchKernelGGL(pb_zero_kernel, dim3(gridN), dim3(OCN_BLOCK), 0, st, L.cursor, (i64)N);
+  hipLaunchKernelGGL(pb_zero_kernel, dim3(1), dim3(OCN_BLOCK), 0, st, L.tickets, (i64)(4 + L.sw / 4));
+#define PB_ENTRIES(FILL)                                                                                              \
+  hipLaunchKernelGGL((pb_entries_kernel<FILL>), dim3(gridB), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA, colA,      \
+                     (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, (i64)flags_cap,               \
+                     (const i64*)L.col_off, L.cursor, L.keys)
+  PB_ENTRIES(false);
+  int rc = ocn_scan_i32(L.cursor, N, (int64_t*)L.col_off, L.scan_ws, (void*)st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pb_zero_kernel, dim3(gridN), dim3(OCN_BLOCK), 0, st, L.cursor, (i64)N);
+  PB_ENTRIES(true);
+#undef PB_ENTRIES
+  hipLaunchKernelGGL(cc_sort_short_kernel, dim3(gridW), dim3(OCN_BLOCK), 0, st, (const i64*)L.col_off, (i64)N, L.keys,
+                     (int32_t*)nullptr, L.long_list, L.tickets);
+  hipLaunchKernelGGL(cc_sort_long_kernel, dim3(256), dim3(OCN_BLOCK), 0, st, (const i64*)L.col_off, L.keys, (int32_t*)nullptr,
+                     (const int32_t*)L.long_list, (const int32_t*)L.tickets, L.tickets + 1);
+  return launch_status();
+}
+
+int64_t ocn_cn_gather_backward_det_keys_offset(int64_t N) {
+  return pb_align((N + 1) * 8) + 2 * pb_align(N * 4) + 16 + pb_align(ocn_scan_workspace_bytes(N));
+}
+
+int ocn_cn_gather_backward_det_lists(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
+                                     int64_t B, const int64_t* off, const uint8_t* flags, int64_t flags_cap, int64_t N,
+                                     void* workspace, void* stream) {
+  if (B < 0 || N < 0 || flags_cap < 0 || flags_cap + 2 * B > 0x7fffffffll) return OCN_EINVAL;
+  if (B == 0 || N == 0) return 0;
+  if (!rowptrA || !src || !dst || !off || !flags || !workspace) return OCN_EINVAL;
+  return pb_build_lists(rowptrA, colA, src, dst, B, off, flags, flags_cap, N, workspace, (hipStream_t)stream);
+}
+
 int ocn_cn_gather_backward_det(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
                                int64_t B, const int64_t* off, const uint8_t* flags, const int32_t* wc, int64_t flags_cap,
                                const float* weights, const float* h, int64_t N, int32_t H, const float* g1,
@@ -144,36 +197,13 @@ int ocn_cn_gather_backward_det(const int64_t* rowptrA, const int32_t* colA, cons
   if (B == 0 || N == 0) return 0;
   if (!rowptrA || !src || !dst || !off || !flags || !weights || !h || !g1 || !g2 || !g3 || !dh || !workspace) return OCN_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  char* ws = (char*)workspace;
-  const int64_t a = pb_align((N + 1) * 8), b = pb_align(N * 4), sw = pb_align(ocn_scan_workspace_bytes(N));
-  i64* col_off = (i64*)ws;
-  int32_t* cursor = (int32_t*)(ws + a);
-  int32_t* long_list = (int32_t*)(ws + a + b);
-  int32_t* tickets = (int32_t*)(ws + a + 2 * b);
-  void* scan_ws = (void*)(ws + a + 2 * b + 16);
-  int32_t* keys = (int32_t*)(ws + a + 2 * b + 16 + sw);
-  const int gridN = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
-  const int gridB = grid_for((B + OCN_WPB - 1) / OCN_WPB, 1 << 16);
-  const int gridW = grid_for((N + OCN_WPB - 1) / OCN_WPB, 1 << 15);
-  hipLaunchKernelGGL(pb_zero_kernel, dim3(gridN), dim3(OCN_BLOCK), 0, st, cursor, (i64)N);
-  hipLaunchKernelGGL(pb_zero_kernel, dim3(1), dim3(OCN_BLOCK), 0, st, tickets, (i64)(4 + sw / 4));
-#define PB_ENTRIES(FILL)                                                                                              \
-  hipLaunchKernelGGL((pb_entries_kernel<FILL>), dim3(gridB), dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA, colA,      \
-                     (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, (i64)flags_cap,               \
-                     (const i64*)col_off, cursor, keys)
-  PB_ENTRIES(false);
-  int rc = ocn_scan_i32(cursor, N, (int64_t*)col_off, scan_ws, stream);
+  int rc = pb_build_lists(rowptrA, colA, src, dst, B, off, flags, flags_cap, N, workspace, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(pb_zero_kernel, dim3(gridN), dim3(OCN_BLOCK), 0, st, cursor, (i64)N);
-  PB_ENTRIES(true);
-#undef PB_ENTRIES
-  hipLaunchKernelGGL(cc_sort_short_kernel, dim3(gridW), dim3(OCN_BLOCK), 0, st, (const i64*)col_off, (i64)N, keys,
-                     (int32_t*)nullptr, long_list, tickets);
-  hipLaunchKernelGGL(cc_sort_long_kernel, dim3(256), dim3(OCN_BLOCK), 0, st, (const i64*)col_off, keys, (int32_t*)nullptr,
-                     (const int32_t*)long_list, (const int32_t*)tickets, tickets + 1);
+  const PbLayout L = pb_layout(workspace, N);
+  const int gridW = grid_for((N + OCN_WPB - 1) / OCN_WPB, 1 << 15);
 #define PB_ACC(NV)                                                                                                   \
-  hipLaunchKernelGGL((pb_accumulate_kernel<NV>), dim3(gridW), dim3(OCN_BLOCK), 0, st, (const i64*)col_off,          \
-                     (const int32_t*)keys, (i64)N, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, wc, \
+  hipLaunchKernelGGL((pb_accumulate_kernel<NV>), dim3(gridW), dim3(OCN_BLOCK), 0, st, (const i64*)L.col_off,        \
+                     (const int32_t*)L.keys, (i64)N, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, wc, \
                      (i64)flags_cap, (const float4*)weights, h, (int)H, g1, g2, g3, dh)
   if (H <= 256) PB_ACC(1); else PB_ACC(2);
 #undef PB_ACC

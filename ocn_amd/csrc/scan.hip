@@ -63,12 +63,14 @@ __global__ __launch_bounds__(OCN_BLOCK) void class_scatter(ClassOfSlot op, i64 B
                                                            i64* __restrict__ order_out, i64* __restrict__ inv_out,
                                                            i64* __restrict__ ranges) {
   const i64 tot = prefix[B];
-  const i64 n3 = tot & CLS_MASK, n2 = (tot >> CLS_BITS) & CLS_MASK, n1 = (tot >> (2 * CLS_BITS)) & CLS_MASK;
+  const bool poisoned = tot < 0;             // the scan gave up (scan_chained): every row "has both kinds of entry", nothing is skipped
+  const i64 n3 = poisoned ? B : (tot & CLS_MASK), n2 = poisoned ? 0 : ((tot >> CLS_BITS) & CLS_MASK),
+            n1 = poisoned ? 0 : ((tot >> (2 * CLS_BITS)) & CLS_MASK);
   for (i64 slot = (i64)blockIdx.x * blockDim.x + threadIdx.x; slot < B; slot += (i64)gridDim.x * blockDim.x) {
     const i64 p = prefix[slot];
     const i64 b3 = p & CLS_MASK, b2 = (p >> CLS_BITS) & CLS_MASK, b1 = (p >> (2 * CLS_BITS)) & CLS_MASK;
     const int c = op.cls(slot);
-    const i64 pos = c == 3 ? b3 : (c == 2 ? n3 + b2 : (c == 1 ? n3 + n2 + b1 : n3 + n2 + n1 + (slot - b3 - b2 - b1)));
+    const i64 pos = poisoned ? slot : (c == 3 ? b3 : (c == 2 ? n3 + b2 : (c == 1 ? n3 + n2 + b1 : n3 + n2 + n1 + (slot - b3 - b2 - b1))));
     const i64 e = op.order ? op.order[slot] : slot;
     order_out[pos] = e;
     inv_out[e] = pos;
@@ -154,8 +156,17 @@ struct PrepExtra {
 // sums the granules of ALL earlier tiles, 64 per round, polling the ones not yet published.  The last workgroup
 // to finish clears the state, so the workspace is left as it was found: ZERO (ocn_scan_workspace_bytes; the
 // caller zeroes it once, when it allocates it).  state[0] = ticket, state[1] = finished tiles, state[2 + t] = tile t.
+//
+// A workspace that was NOT zero on entry (the caller's contract broken: a workspace shared by two launches in flight, a
+// buffer that was never cleared) cannot be scanned: tickets start beyond the launch or a granule never turns ready.
+// The launch then neither hangs nor traps (a trap aborts the caller's process): the poll is bounded, a tile that gives
+// up publishes SCAN_ERR so that its successors give up at once, writes ZERO offsets for its own items (every consumer
+// indexes with them: zero and the good tiles' prefixes stay inside the true total) and the grand total out[n] becomes
+// OCN_SCAN_POISON (-1).  Consumers test out[n] < 0: the intersection kernels raise bit OCN_ST_SCAN of their status words and
+// leave, the processing / class orders fall back to batch order, the host raises where it reads a total.
 #define SCAN_READY (1ull << 63)
-#define SCAN_SPIN_MAX (1 << 24)     /* polls of one predecessor granule before the launch gives up — loudly (below) */
+#define SCAN_ERR (1ull << 62)
+#define SCAN_SPIN_MAX (1 << 20)     /* polls of one predecessor granule (~0.5 us each) before the tile gives up */
 template <typename Op, typename Extra = NoExtra>
 __global__ __launch_bounds__(OCN_BLOCK) void scan_chained(Op op, i64 n, i64* __restrict__ out, u64* __restrict__ state,
                                                           i64 nt, const Extra extra = Extra()) {
@@ -165,10 +176,18 @@ __global__ __launch_bounds__(OCN_BLOCK) void scan_chained(Op op, i64 n, i64* __r
     extra((i64)blockIdx.x - nt, (i64)gridDim.x - nt);
     return;
   }
-  if (threadIdx.x == 0) s_tile = (i64)atomicAdd(&state[0], 1ull);
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) { s_tile = (i64)atomicAdd(&state[0], 1ull); s_bad = 0; }
   __syncthreads();
   const i64 t = s_tile;
-  if (t < 0 || t >= nt) __builtin_trap();     // a ticket outside the launch: the workspace was not zero (caller's contract)
+  if (t < 0 || t >= nt) {                     // a ticket outside the launch: the workspace was not zero
+    if (threadIdx.x == 0) out[n] = OCN_SCAN_POISON;
+    for (int q = 0; q < SCAN_IPT; ++q) {      // (best effort: the tile this workgroup would have had in dispatch order reads as zeros)
+      const i64 e = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_IPT + q;
+      if (e < n) out[e] = 0;
+    }
+    return;
+  }
   const i64 base = t * SCAN_TILE + (i64)threadIdx.x * SCAN_IPT;      // thread-contiguous items: prefix order = item order
   i64 v[SCAN_IPT];
   i64 s = 0;
@@ -184,37 +203,41 @@ __global__ __launch_bounds__(OCN_BLOCK) void scan_chained(Op op, i64 n, i64* __r
     __hip_atomic_store(&state[2 + t], SCAN_READY | (u64)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x < OCN_WAVE) {
     i64 prefix = 0;
-    for (i64 p0 = 0; p0 < t; p0 += OCN_WAVE) {
+    bool bad = false;
+    for (i64 p0 = 0; p0 < t && !bad; p0 += OCN_WAVE) {
       const i64 p = p0 + threadIdx.x;
       u64 w = SCAN_READY;
       if (p < t) {
         // Tickets are drawn in order, so every tile p < t belongs to a workgroup that is already running and publishes its
         // granule before it waits for anything itself (tile 0 waits for nobody, tile p only for tiles < p): with a ZERO
-        // workspace (the caller's contract) the wait always ends.  A workspace that was not zero can leave a granule that
-        // never turns ready; the poll is bounded so that this cannot hang the GPU, and giving up is a trap (the process
-        // aborts with a GPU exception) rather than a prefix sum made of whatever was read last — wrong offsets would
-        // otherwise reach the flag layout, the processing order and the column lists without any sign.
+        // workspace (the caller's contract) the wait always ends, after microseconds.
         int spins = 0;
         do {
           w = __hip_atomic_load(&state[2 + p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (!(w & SCAN_READY)) __builtin_amdgcn_s_sleep(1);
-        } while (!(w & SCAN_READY) && ++spins < SCAN_SPIN_MAX);
-        if (!(w & SCAN_READY)) __builtin_trap();
+          if (!(w & (SCAN_READY | SCAN_ERR))) __builtin_amdgcn_s_sleep(1);
+        } while (!(w & (SCAN_READY | SCAN_ERR)) && ++spins < SCAN_SPIN_MAX);
       }
-      prefix += (i64)(w & ~SCAN_READY);
+      bad = __ballot(!(w & SCAN_READY) || (w & SCAN_ERR)) != 0ull;
+      prefix += (i64)(w & ~(SCAN_READY | SCAN_ERR));
     }
     prefix = wave_sum(prefix);
-    if (threadIdx.x == 0) s_prefix = prefix;
+    if (threadIdx.x == 0) {
+      s_prefix = prefix;
+      s_bad = bad;
+      if (bad)                                 // successors still polling give up at once instead of timing out themselves
+        __hip_atomic_store(&state[2 + t], SCAN_READY | SCAN_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   __syncthreads();
+  const bool failed = s_bad != 0;
   ex += s_prefix;
 #pragma unroll
   for (int q = 0; q < SCAN_IPT; ++q) {
     const i64 e = base + q;
-    if (e < n) out[e] = ex;
+    if (e < n) out[e] = failed ? 0 : ex;
     ex += v[q];
   }
-  if (t == nt - 1 && threadIdx.x == 0) out[n] = s_prefix + tot;
+  if (t == nt - 1 && threadIdx.x == 0) out[n] = failed ? OCN_SCAN_POISON : s_prefix + tot;
   // the last workgroup to get here has no reader left behind it: leave the state zero for the next call
   __syncthreads();
   if (threadIdx.x == 0) s_tile = (i64)atomicAdd(&state[1], 1ull);
@@ -248,11 +271,13 @@ __global__ __launch_bounds__(OCN_BLOCK) void order_count(const i64* __restrict__
 
 // (the counters were consumed by the scan: each row clears the one it raised, so the workspace is left zero)
 __global__ __launch_bounds__(OCN_BLOCK) void order_scatter(const i64* __restrict__ node, i64 B,
-                                                           unsigned long long* __restrict__ cursor,
+                                                           unsigned long long* __restrict__ cursor, const i64* __restrict__ total,
                                                            i64* __restrict__ order, int32_t* __restrict__ counts) {
+  const bool poisoned = total[0] < 0;        // the scan of the counters gave up (scan_chained): batch order — any order is a correct one
   for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < B; e += (i64)gridDim.x * blockDim.x) {
     const i64 v = node[e];
-    order[atomicAdd(cursor + v, 1ull)] = e;
+    if (poisoned) order[e] = e;
+    else order[atomicAdd(cursor + v, 1ull)] = e;
     counts[v] = 0;
   }
 }
@@ -345,7 +370,7 @@ int ocn_order_by_node_finish(const int64_t* node, int64_t B, int64_t n_nodes, in
   int rc = run_scan(op, (i64)n_nodes, offs, scan_ws, st);
   if (rc) return rc;
   hipLaunchKernelGGL(order_scatter, dim3(grid), dim3(OCN_BLOCK), 0, st, (const i64*)node, (i64)B,
-                     (unsigned long long*)offs, (i64*)order, counts);
+                     (unsigned long long*)offs, (const i64*)(offs + n_nodes), (i64*)order, counts);
   return launch_status();
 }
 

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(WG_THREADS) void walk_prep_kernel(
     cnt1[e] = 0;
     cnt2[e] = 0;
   }
-  if (t < 4) { status[t] = 0; scal[t] = 0; }
+  if (t < 4) { if (t < 3) status[t] = 0; scal[t] = 0; }      // (status[3] is the caller's sticky error word)
   __syncthreads();
   // flag offsets: exclusive scan of deg(src) in BATCH order
   const i64 total = wgp_scan<WG_MAX_B / WG_THREADS>(s_a, B, s_tmp);

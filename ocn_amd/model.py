@@ -569,6 +569,22 @@ class _CNPredictorBase(nn.Module):
         xcn1, xcn2, xij = self._pool(st, w, x)
         return self._heads(x, xcn1, xcn2, xij, getattr(st, "cls", None))
 
+    def check_errors(self) -> None:
+        """Read the STICKY status words of this predictor's scratch sets (one host sync) and raise for what the batches since
+        the last check left there: a flag buffer that was too small, offsets from a scan whose workspace was not zero
+        (ocn_hip.h: OCN_ST_CAP / OCN_ST_SCAN).  The scoring loops call it once per split; a driver that calls ``forward`` per
+        batch can call it whenever it reads scores anyway."""
+        words = [t for d in ([self._ws] + list(getattr(self, "_ws_slots", ()))) for k, t in d.items() if k[0] == "status"]
+        if not words:
+            return
+        bits = 0
+        for v in torch.stack([t[3] for t in words]).tolist():
+            bits |= int(v)
+        if bits:
+            for t in words:
+                t[3:].zero_()
+            raise RuntimeError(ops.status_message(bits))
+
     def _class_order(self, st, x) -> None:
         """Class-major rows (candidates without cn1 / cn2 entries end up in contiguous ranges the heads skip) where
         that pays; sets ``st.cls`` (None = batch order)."""
@@ -968,11 +984,18 @@ class CNLinkPredictorbaselearn(_CNPredictorBase):
         n = adj.size(0)
         if t2.nnz() * 2 < n * n or adj.size(1) != x.shape[0] or n != x.shape[0]:
             return None
-        key = (x.data_ptr(), x._version, tuple(x.shape), id(adj))
+        # Keyed on the live tensor OBJECTS (weak references) and x's version counter, never on addresses: the drivers' test()
+        # computes a fresh h = model(x, adj) per evaluation, and the caching allocator hands the new h the freed one's
+        # address (a data_ptr key then matched and the pooling copied the previous epoch's row sums).
+        import weakref
         hit = getattr(self, "_rowsum_cache", None)
-        if hit is None or hit[0] != key:
-            hit = self._rowsum_cache = (key, ops.spmm_csr(adj._rowptr, adj._col, x), adj)      # (adj kept: its id stays its own)
-        return hit[1]
+        if (hit is None or hit[0]() is not x or hit[1] != x._version or hit[2]() is not adj
+                or hit[3] != (x.data_ptr(), tuple(x.shape))):
+            if torch.cuda.is_current_stream_capturing() and hit is not None:
+                raise RuntimeError("embeddings changed since the last eager call: run one eager batch before capturing")
+            hit = self._rowsum_cache = (weakref.ref(x), x._version, weakref.ref(adj), (x.data_ptr(), tuple(x.shape)),
+                                        ops.spmm_csr(adj._rowptr, adj._col, x))
+        return hit[4]
 
     def forward(self, x, adj, cn1, cn2, tar_ei, filled1: bool = False):
         # the drivers pass the argparse Namespace in this slot (NeighborOverlap_large.py:122)

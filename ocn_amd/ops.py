@@ -87,6 +87,23 @@ def _req(t: Tensor, dtype, name: str, ndim: Optional[int] = None) -> Tensor:
     return t
 
 
+ST_CAP, ST_SCAN = 1, 2             # include/ocn_hip.h: OCN_ST_CAP, OCN_ST_SCAN (bits of status[0] and of the sticky status[3])
+
+
+def _total(t: Tensor) -> int:
+    """The grand total of a scan read on the host.  Negative = OCN_SCAN_POISON: the scan's workspace was not zero on entry
+    (ocn_hip.h, ocn_scan_workspace_bytes) — a Python error here, where round 3 ended in a GPU trap."""
+    v = int(t.item())
+    if v < 0:
+        raise _lib.OcnHipError("scan workspace was not zero on entry (two launches in flight on one workspace?)")
+    return v
+
+
+def status_message(bits: int) -> str:
+    return "; ".join(m for b, m in ((ST_CAP, "CN flag buffer capacity exceeded"),
+                                    (ST_SCAN, "a scan workspace was not zero on entry: the batch's offsets are void")) if bits & b)
+
+
 def _ws(n: int, device) -> Tensor:
     return torch.zeros(int(_lib.lib().ocn_scan_workspace_bytes(n)) // 8 + 1, dtype=torch.int64, device=device)
 
@@ -239,10 +256,10 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     hist = buf(wsd, "hist", (n_cols, 2), torch.int64, dev)
     cnt1 = buf(wsd, "cnt1", B, torch.int32, dev)
     cnt2 = buf(wsd, "cnt2", B, torch.int32, dev) if (walk or t2 is not None) else None
-    status = buf(wsd, "status", 4, torch.int32, dev)     # [0] overflow flag; [1], [2] walk-route work tickets
+    status = buf(wsd, "status", 4, torch.int32, dev, zero_init=True)     # [0] error bits of this batch; [1], [2] walk-route work tickets; [3] sticky error bits
     scal = buf(wsd, "scal", 4, torch.int32, dev)         # the column statistics word of the weights stage
     # the flag offsets, the counting phase of the order and the batch's resets: ONE launch (ocn_batch_prep)
-    zs = [t for t in [hist, status, scal] + ([cnt1, cnt2] if walk else []) if t is not None and t.numel()]
+    zs = [t for t in [hist, status[:3], scal] + ([cnt1, cnt2] if walk else []) if t is not None and t.numel()]     # (status[3]: sticky)
     if sched is not None:             # group costs for the pooling's schedule (ocn_hip.h: ocn_cn_flags `gcost`): first half of `sched`
         if rec is None or walk or _req(sched, torch.int32, "sched", 1).numel() < 2 * ((B + 3) // 4):
             raise ValueError("sched: int32[2 * ceil(B / 4)] beside the slot records of the pattern route")
@@ -254,7 +271,7 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
         check(_lib.lib().ocn_order_by_node_finish(ptr(src), B, n_src, ptr(order), ptr(ows), stream_ptr()),
               "ocn_order_by_node_finish")
     bound = B * max(int(max_deg_a), 0)
-    cap = bound if bound <= FLAGS_NOSYNC_LIMIT else int(off[-1].item())
+    cap = bound if bound <= FLAGS_NOSYNC_LIMIT else _total(off[-1])
     flags = buf(wsd, "flags", max(cap, 1), torch.uint8, dev)
     wc = buf(wsd, "wc", max(cap, 1), torch.int32, dev) if walk else None
     chunk_off = rev_off = None
@@ -320,14 +337,14 @@ def _cn_flags_walk_small(rowptrA, colA, src, dst, n_cols, max_deg_a, wsd, nds):
     hist = buf(wsd, "hist", (n_cols, 2), torch.int64, dev)
     cnt1 = buf(wsd, "cnt1", B, torch.int32, dev)
     cnt2 = buf(wsd, "cnt2", B, torch.int32, dev)
-    status = buf(wsd, "status", 4, torch.int32, dev)
+    status = buf(wsd, "status", 4, torch.int32, dev, zero_init=True)     # ([3]: the sticky error word, never cleared by the library)
     scal = buf(wsd, "scal", 4, torch.int32, dev)
     check(l.ocn_walk_prep(ptr(rowptrA), ptr(nds), ptr(src), ptr(dst), B, int(walk_share_min), ptr(order), ptr(off),
                           ptr(chunk_off), ptr(rev_off), ptr(g_head), ptr(g_item_off), ptr(g_active), ptr(meta), ptr(cnt1),
                           ptr(cnt2), ptr(status), ptr(scal), stream_ptr()), "ocn_walk_prep")
     zero_regions([hist])
     bound = B * max(int(max_deg_a), 0)
-    cap = bound if bound <= FLAGS_NOSYNC_LIMIT else int(off[-1].item())
+    cap = bound if bound <= FLAGS_NOSYNC_LIMIT else _total(off[-1])
     flags = buf(wsd, "flags", max(cap, 1), torch.uint8, dev)
     wc = buf(wsd, "wc", max(cap, 1), torch.int32, dev)
     _mark("cn_prep")
@@ -467,6 +484,7 @@ def gather_schedule(sched: Tensor, B: int) -> bool:
         return False
     n_groups = B // 4
     check(_lib.lib().ocn_gather_schedule(ptr(sched), n_groups, ptr(sched[n_groups:]), stream_ptr()), "ocn_gather_schedule")
+    _mark("cn_sched")
     return True
 
 
@@ -557,6 +575,20 @@ def cn_gather_backward(rowptrA, colA, src, dst, off, flags, wc, weights: Tensor,
     return dh
 
 
+@_on_device
+def cn_gather_backward_lists(rowptrA, colA, src, dst, off, flags, N: int):
+    """The per-node key lists of the deterministic pooling backward (ocn_hip.h: ocn_cn_gather_backward_det_lists), for
+    inspection: (col_off int64 [N + 1], keys int32 [col_off[N]]).  One host sync (the list total)."""
+    l = _lib.lib()
+    B, cap = src.numel(), flags.numel()
+    ws = torch.empty(int(l.ocn_cn_gather_backward_det_workspace_bytes(N, B, cap)), dtype=torch.uint8, device=src.device)
+    check(l.ocn_cn_gather_backward_det_lists(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), B, ptr(off), ptr(flags), cap, N, ptr(ws),
+                                             stream_ptr()), "ocn_cn_gather_backward_det_lists")
+    col_off = ws[: (N + 1) * 8].view(torch.int64)
+    k0 = int(l.ocn_cn_gather_backward_det_keys_offset(N))
+    return col_off, ws[k0: k0 + 4 * _total(col_off[N])].view(torch.int32)
+
+
 SPMM_MODES = {"sum": 0, "add": 0, "mean": 1, "max": 2}
 
 
@@ -622,7 +654,7 @@ def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int):
     check(l.ocn_spgemm_pattern_count(ptr(rowptrA), ptr(colA), n, ptr(rowptrB), ptr(colB), n_cols_b,
                                      ptr(cnt), ptr(bitmap), words, stream_ptr()), "ocn_spgemm_pattern_count")
     rowptrC = scan_i32(cnt)
-    nnz = int(rowptrC[-1].item())
+    nnz = _total(rowptrC[-1])
     colC = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
     if nnz:
         check(l.ocn_spgemm_pattern_fill(ptr(rowptrA), ptr(colA), n, ptr(rowptrB), ptr(colB), n_cols_b,
@@ -658,7 +690,7 @@ def dense_block_adj2(rowptr: Tensor, col: Tensor, n: int, block_size: int, fold:
     cnt = torch.empty(n, dtype=torch.int32, device=dev)
     check(l.ocn_bitrows_count(ptr(bits), words, n, n, ptr(cnt), stream_ptr()), "ocn_bitrows_count")
     rowptrC = scan_i32(cnt)
-    nnz = int(rowptrC[-1].item())
+    nnz = _total(rowptrC[-1])
     colC = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
     if nnz:
         check(l.ocn_bitrows_fill(ptr(bits), words, n, n, ptr(rowptrC), ptr(colC), stream_ptr()), "ocn_bitrows_fill")
@@ -909,8 +941,10 @@ def coo_to_csr(row: Tensor, col: Tensor, n_rows: int, n_cols: int, symmetrize: b
     check(l.ocn_coo_to_csr(ptr(row), ptr(col), nnz, n_rows, n_cols, int(symmetrize), int(dedupe), ptr(rowptr), ptr(out),
                            ptr(ws), ptr(res), stream_ptr()), "ocn_coo_to_csr")
     n_out, bad = (int(v) for v in res.tolist())
-    if bad and check_range:
+    if bad:          # (the status is on the host anyway: out-of-range entries are never dropped silently; `check_range` kept for callers)
         raise IndexError("SparseTensor: index out of range for sparse_sizes")
+    if n_out < 0:
+        raise _lib.OcnHipError("ocn_coo_to_csr: scan state was not zero")
     return rowptr, out[:n_out]
 
 

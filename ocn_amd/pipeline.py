@@ -36,6 +36,9 @@ def score_edges(predictor, h: Tensor, adj, adj2, edges: Tensor, batch_size: int,
     outs, done = [], []
     if edges.shape[0] == 0:
         return h.new_zeros(0)
+    # the adjacency's lazy caches (bit rows, longest row) are built HERE, on the caller's stream, before the loop forks its
+    # side streams: two phase-A streams must never race on a half-built cache (the caches also carry their own events)
+    adj.warm(walk=False)
     # the ids of the whole split are bounds-checked once; the batches then run without a host sync each
     with ops.prevalidated(edges[:, 0], edges[:, 1], adj.size(0), adj.size(0)):
         perms = list(PermIterator(edges.device, edges.shape[0], batch_size, training=False))
@@ -48,10 +51,13 @@ def score_edges(predictor, h: Tensor, adj, adj2, edges: Tensor, batch_size: int,
             if len(done) >= max(run_ahead, 1):
                 done.pop(0).synchronize()
 
-        for out in overlapped_steps(begin, lambda tok: predictor.finish(h, tok, args), len(perms), before_step=flow, batch=batch_size):
+        for out in overlapped_steps(begin, lambda tok: predictor.finish(h, tok, args), len(perms), before_step=flow, batch=batch_size,
+                                    device=h.device):
             outs.append(out.reshape(-1))
             done.append(torch.cuda.current_stream(h.device).record_event())
-    return torch.cat(outs, dim=0)
+    scores = torch.cat(outs, dim=0)
+    predictor.check_errors()       # the batches' sticky status words, read once per split (flag capacity, scan state)
+    return scores
 
 
 @torch.no_grad()
@@ -70,6 +76,7 @@ def score_mrr_split(predictor, h: Tensor, adj, source: Tensor, target: Tensor, t
         outs = []
         if src_all.numel() == 0:
             return h.new_zeros(0)
+        adj.warm(walk=True)            # (degree sums of the two-sided sweep: built on the caller's stream, before the side streams fork)
         with ops.prevalidated(src_all, dst_all, adj.size(0), adj.size(0)):
             perms = list(PermIterator(src_all.device, src_all.shape[0], batch_size, training=False))
 
@@ -78,9 +85,12 @@ def score_mrr_split(predictor, h: Tensor, adj, source: Tensor, target: Tensor, t
                 cn1, cn2 = get_cn1_cn2(adj, e)
                 return predictor.begin(h, adj, cn1, cn2, e, slot=it, args=args)
 
-            for out in overlapped_steps(begin, lambda tok: predictor.finish(h, tok, args), len(perms), batch=batch_size):
+            for out in overlapped_steps(begin, lambda tok: predictor.finish(h, tok, args), len(perms), batch=batch_size,
+                                        device=h.device):
                 outs.append(out.reshape(-1))
-        return torch.cat(outs, dim=0)
+        scores = torch.cat(outs, dim=0)
+        predictor.check_errors()
+        return scores
 
     pos_pred = run(source, target)
     n_neg = target_neg.shape[1]
@@ -100,7 +110,8 @@ def _side_stream(index: int, q: int = 0):
     return s
 
 
-def overlapped_steps(begin, finish, n_steps: int, before_step=None, after_step=None, overlap=None, batch: Optional[int] = None):
+def overlapped_steps(begin, finish, n_steps: int, before_step=None, after_step=None, overlap=None, batch: Optional[int] = None,
+                     device=None):
     """Generator over ``finish(begin(it))`` for it = 0 .. n_steps - 1 with TWO batches in flight: ``begin(it + 1)`` (the
     predictor's phase A: the intersection pass, scratch set ``it & 1``) is enqueued before ``finish(it)`` (phase B:
     weights, pooling, heads) — and, on a GPU, on a SECOND HIP stream, so that the latency-bound intersection kernels of
@@ -108,7 +119,8 @@ def overlapped_steps(begin, finish, n_steps: int, before_step=None, after_step=N
     MI355X: collab shape 0.507 -> 0.474 ms per batch, ddi 0.629 -> 0.488, ppa 0.564 -> 0.439; same scores).  Events order
     the two streams: phase B of batch t waits for phase A of batch t; phase A of batch t + 2 waits for phase B of batch t
     (they share a scratch set).  ``overlap`` = None: ``ops.overlap_streams`` where CUDA/HIP is up and the batch has at least
-    ``ops.overlap_min_batch`` candidates (``batch``: per-rank batch size, if known), else one stream."""
+    ``ops.overlap_min_batch`` candidates (``batch``: per-rank batch size, if known), else one stream.  ``device``: the device
+    of the tensors the two phases work on (default: the current device) — the streams and events are created there."""
     if overlap is None:
         overlap = (bool(ops.overlap_streams) and torch.cuda.is_available() and torch.cuda.is_initialized()
                    and (batch is None or batch >= ops.overlap_min_batch))
@@ -123,8 +135,11 @@ def overlapped_steps(begin, finish, n_steps: int, before_step=None, after_step=N
             if after_step is not None:
                 after_step(it)
         return
-    main = torch.cuda.current_stream()
-    index = main.device.index if main.device.index is not None else torch.cuda.current_device()
+    index = torch.cuda.current_device() if device is None else (torch.device(device).index if torch.device(device).index is not None
+                                                                 else torch.cuda.current_device())
+    # (tensors on another device than the current one, ADVICE r3: the ops launch on THEIR device's current stream —
+    # ops._on_device — so the loop's main stream, side streams and events are that device's, whatever the current device is)
+    main = torch.cuda.current_stream(index)
     # batches in flight: depth - 1 in phase A, one in phase B
     depth = max(2, int(ops.overlap_depth)) if (batch is not None and batch <= ops.overlap_deep_max_batch) else 2
     sides = [_side_stream(index, q) for q in range(depth - 1)]
@@ -138,12 +153,15 @@ def overlapped_steps(begin, finish, n_steps: int, before_step=None, after_step=N
         with torch.cuda.stream(sd):
             if it >= depth:
                 sd.wait_event(done[it % depth])        # phase B of batch it - depth read the scratch set this batch overwrites
-            tok = begin(it)
+            was_active, ops._overlap_active = ops._overlap_active, True      # (predictor.begin: the sharded collective then starts in
+            try:                                                            # phase B; set around begin() only — the consumer's own
+                tok = begin(it)                                             # calls between two yields must not see it)
+            finally:
+                ops._overlap_active = was_active
             begun[it % depth].record(sd)
         return tok
 
     ahead = []                                             # tokens of the batches already in phase A, oldest first
-    was_active, ops._overlap_active = ops._overlap_active, True      # (predictor.begin: the sharded collective then starts in phase B)
     try:
         for it in range(n_steps):
             if before_step is not None:
@@ -158,7 +176,6 @@ def overlapped_steps(begin, finish, n_steps: int, before_step=None, after_step=N
             if after_step is not None:
                 after_step(it)
     finally:
-        ops._overlap_active = was_active
         for sd in sides:
             main.wait_stream(sd)
 

@@ -94,6 +94,7 @@ class SparseTensor:
         self._maxdeg: Optional[int] = None
         self._bitmap: Optional[Tensor] = None
         self._nds: Optional[Tensor] = None
+        self._ready: dict = {}                 # cache name -> event recorded behind its asynchronous build
         self.storage = _Storage(self)
 
     # ---- constructors ------------------------------------------------------------------
@@ -168,6 +169,27 @@ class SparseTensor:
             self._maxdeg = int((self._rowptr[1:] - self._rowptr[:-1]).max()) if self._sizes[0] else 0
         return self._maxdeg
 
+    # The caches below are built ASYNCHRONOUSLY on whatever stream is current at their first use.  A scoring loop runs its
+    # batches on several streams (pipeline.overlapped_steps): the stream that finds the cache filled must not read it
+    # before the stream that is still filling it is done, so each cache carries the event recorded behind its build and
+    # every later reader's stream waits for it — until the event has completed, after which it is dropped.
+    def _published(self, name: str) -> None:
+        if self._col.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self._col.device))
+            self._ready[name] = ev
+
+    def _await(self, name: str) -> None:
+        ev = self._ready.get(name)
+        if ev is None:
+            return
+        if torch.cuda.is_current_stream_capturing():       # (no event query while capturing; the warm-up passes ran before it)
+            return
+        if ev.query():
+            del self._ready[name]
+        else:
+            torch.cuda.current_stream(self._col.device).wait_event(ev)
+
     def bit_rows(self) -> Optional[Tensor]:
         """The pattern as dense bit rows (cached, built once by ocn_bitrows_from_csr) when they fit
         ``ops.a1_bitmap_max_bytes``, else None: what the intersection kernel probes instead of searching a row
@@ -176,15 +198,36 @@ class SparseTensor:
             n, m = self._sizes
             if 0 < n * ((m + 31) // 32) * 4 <= ops.a1_bitmap_max_bytes:
                 self._bitmap = ops.bitrows_from_csr(self._rowptr, self._col, m)
+                self._published("bitmap")
+        else:
+            self._await("bitmap")
         return self._bitmap
 
     def neighbor_degree_sum(self) -> Tensor:
         """Σ_{u∈N(v)} deg(u) per node, cached: lets the walk-count route sweep each candidate edge from
         its cheaper endpoint (ocn_hip.h: ocn_neighbor_degree_sum).  Square adjacencies only."""
         if self._nds is None:
-            from . import ops
             self._nds = ops.neighbor_degree_sum(self._rowptr, self._col)
+            self._published("nds")
+        else:
+            self._await("nds")
         return self._nds
+
+    def product_bit_rows(self) -> Optional[Tensor]:
+        """The bit rows this matrix ARRIVED with (``A @ A``, the block route), never built on demand: A² of a large graph
+        only has them when they fit ``ops.a2_bitmap_max_bytes`` at construction."""
+        if self._bitmap is not None:
+            self._await("bitmap")
+        return self._bitmap
+
+    def warm(self, walk: bool = False) -> None:
+        """Build the lazy caches a candidate batch reads (bit rows, longest row, the walk route's degree sums) on the
+        CURRENT stream: what a scoring loop calls before it forks its side streams."""
+        self.max_rowcount()
+        if walk:
+            self.neighbor_degree_sum()
+        else:
+            self.bit_rows()
 
     # ---- device movement ---------------------------------------------------------------
     def to_device(self, device, non_blocking: bool = False) -> "SparseTensor":
@@ -341,6 +384,8 @@ class CooView:
         rowptr, col, bitmap = ops.spgemm_pattern(a._rowptr, a._col, b._rowptr, b._col, b._sizes[1])
         out = SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(a._sizes[0], b._sizes[1]))
         out._bitmap = bitmap                   # dense bit rows of the product, probed by the intersection kernel
+        if bitmap is not None:
+            out._published("bitmap")
         return CooView(out, is_product=True)
 
     def to_torch(self) -> Tensor:

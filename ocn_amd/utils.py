@@ -72,7 +72,7 @@ class CNState:
         (self.order, self.off, self.flags, self.wc, self.hist, self.cnt1, self.cnt2, self.status, self.scal) = ops.cn_flags(
             adj._rowptr, adj._col, None if walk else (t1._rowptr, t1._col),
             None if (walk or t2 is None) else (t2._rowptr, t2._col), self.src, self.dst, self.N,
-            adj.max_rowcount(), walk=walk, t2_bitmap=None if (walk or t2 is None) else t2._bitmap, wsd=ws,
+            adj.max_rowcount(), walk=walk, t2_bitmap=None if (walk or t2 is None) else t2.product_bit_rows(), wsd=ws,
             nds=adj.neighbor_degree_sum() if (walk and ops.walk_two_sided) else None,
             t1_bitmap=None if walk else t1.bit_rows(), rec=self.rec, sched=self.sched)
         self._hist_live = True
@@ -131,8 +131,11 @@ class CNState:
         return st
 
     def check_status(self) -> None:
-        if int(self.status[0].item()) != 0:
-            raise RuntimeError("CN flag buffer capacity exceeded")
+        """Raise for the error bits the intersection pass left for this batch (one host sync; ocn_hip.h: OCN_ST_*)."""
+        bits = int(self.status[0].item())
+        if bits:
+            self.status[3:].zero_()
+            raise RuntimeError(ops.status_message(bits))
 
     def hist_counts(self) -> Tensor:
         """int64 [N, 4] = {n1, n2, n_union, walk-count sum} per column."""
@@ -363,6 +366,7 @@ def block_matrix_multiply(spadj: SparseTensor, block_size: int, fold_quirk: bool
         out = SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(n, n))
         if not fold_quirk:
             out._bitmap = bits                   # dense bit rows of A²: one probe per membership test in the intersection
+            out._published("bitmap")
         return out
     if fold_quirk:
         raise NotImplementedError("fold_quirk needs the dense block route (n <= ops.dense_adj2_max_nodes, block_size % 32 == 0)")

@@ -145,6 +145,38 @@ def _pool_case(n, avg, mx, B, H, seed, walk=False):
 @pytest.mark.parametrize("n,avg,mx,B,H", [(500, 8, 100, 300, 32), (3000, 12, 400, 2048, 64), (20000, 10, 600, 8192, 256),
                                           (2000, 30, 1500, 4096, 128)], ids=lambda v: str(v))
 @pytest.mark.parametrize("name", ["cn5", "cn7"])
+def _assert_backward_key_lists(adj, adj2, e):
+    """Host-side reference of the per-node key lists the deterministic pooling backward accumulates from, checked BEFORE the
+    accumulate pass runs (round 3 chased a GPU memory fault in that pass by re-running it; the lists were
+    verified by hand then — this is that check, kept).  Also every index the accumulate will form from a key is in range."""
+    from ocn_amd.utils import CNState
+    st = CNState(adj, adj, adj2, e)
+    N, B, cap = adj.size(0), st.B, st.flags.numel()
+    col_off, keys = ops.cn_gather_backward_lists(adj._rowptr, adj._col, st.src, st.dst, st.off, st.flags, N)
+    rows = adj[st.src]                                            # row e = N(src[e]), columns ascending
+    r, c, _ = rows.coo()
+    pos = torch.arange(r.numel(), device=DEV) - rows._rowptr[:-1][r] + st.off[:-1][r]
+    live = st.flags[pos] != 0
+    eb = torch.arange(B, device=DEV)
+    node = torch.cat([c[live], st.src, st.dst])
+    key = torch.cat([pos[live], cap + 2 * eb, cap + 2 * eb + 1])
+    want_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=DEV), torch.cumsum(torch.bincount(node, minlength=N), 0)])
+    assert torch.equal(col_off, want_off)
+    assert torch.equal(keys.long(), key[torch.argsort(node * (1 << 32) + key)])
+    k = keys.long()
+    pooled = k < cap
+    row = torch.searchsorted(st.off, k[pooled], right=True) - 1     # the batch row pb_accumulate's binary search finds
+    assert bool((row >= 0).all()) and bool((row < B).all()) and bool((st.flags[k[pooled]] != 0).all())
+    assert bool((k[pooled] < st.off[B]).all())
+    t = k[~pooled] - cap
+    assert bool((t >= 0).all()) and bool(((t >> 1) < B).all())
+    other = torch.where((t & 1) == 1, st.src[t >> 1], st.dst[t >> 1])
+    assert bool((other >= 0).all()) and bool((other < N).all())
+    # the lists are rebuilt identically by a second call on recycled memory (the fault showed on the SECOND call only)
+    col_off2, keys2 = ops.cn_gather_backward_lists(adj._rowptr, adj._col, st.src, st.dst, st.off, st.flags, N)
+    assert torch.equal(col_off2, col_off) and torch.equal(keys2, keys)
+
+
 def test_pooling_backward_is_deterministic_and_equals_the_atomic_form(hiplib, monkeypatch, name, n, avg, mx, B, H):
     """The node-by-node pooling backward (ocn_cn_gather_backward_det): the same bits on every run, and the atomic kernel's
     result to rounding (fp32 sums in another order)."""
@@ -152,6 +184,7 @@ def test_pooling_backward_is_deterministic_and_equals_the_atomic_form(hiplib, mo
     from ocn_amd.utils import adjoverlap
     from types import SimpleNamespace
     adj, adj2, e = _pool_case(n, avg, mx, B, H, seed=n + B)
+    _assert_backward_key_lists(adj, adj2, e)
     torch.manual_seed(1)
     pred = predictor_dict[name](H, H, 1, 3, 0.0, 0.0, True).eval().to(DEV)
     x = torch.randn(n, H, device=DEV)
