@@ -113,11 +113,12 @@ class StageTimer:
 
 
 def sampled_step(it, steps):
-    """Stage events are recorded on at least 8 steps of the timed region whatever --steps is (every max(1, steps // 8)-th),
-    never on step 0: with three batches in flight step 0 PRIMES the pipeline (three phase-A passes are enqueued before its
-    phase B), every later step enqueues exactly one phase A (of batch it + 2) and one phase B (of batch it)."""
-    every = max(1, steps // 8)
-    return it > 0 and it % every == (every - 1 if every > 1 else 0)
+    """Stage events are recorded on 8 steps of the timed region whatever --steps is (all but the first when there are fewer),
+    evenly spread, never on step 0: with three batches in flight step 0 PRIMES the pipeline (three phase-A passes are
+    enqueued before its phase B), every later step enqueues exactly one phase A (of batch it + 2) and one phase B (of batch it)."""
+    if steps <= 9:
+        return it > 0
+    return it in {1 + (q * (steps - 2)) // 7 for q in range(8)}
 
 
 def make_predictor(cfg, dev):
@@ -338,6 +339,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
     ap.add_argument("--no-validate-leg", action="store_true", help="skip the second timed loop with the per-batch id check on")
+    ap.add_argument("--no-one-stream-leg", action="store_true",
+                    help="skip the untimed pass with the streams serialised (the *_one_stream keys): a kernel trace of the command "
+                         "then averages over the overlapped loop only, like the line's own stage events")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as a captured HIP graph (pipeline.GraphedScorer; one GPU, no stage events: "
                          "the roofline objects are then null)")
@@ -431,10 +435,17 @@ def main():
     # Runtime pre-warm (untimed, before the W warm-up steps): the HIP runtime grows its internal
     # command/signal pools in ~35 ms host stalls during the first ~1000 launches of a process; a short
     # --warmup would otherwise put one of them inside the timed region.
-    for i in range(args.prewarm):
-        step(i)
-        if i % 4 == 3:
-            torch.cuda.synchronize()
+    if pipelined and args.prewarm > 0:             # (on the timed loop's own code path too: what a kernel trace of this command averages
+        from ocn_amd.pipeline import pipelined_shard_loop           # over is then the overlapped loop, not a one-stream variant of it)
+        with torch.no_grad():
+            for _ in range(max(args.prewarm // 16, 1)):
+                pipelined_shard_loop(begin, lambda tok: pred.finish(h, tok, wl["args"]), 16, B_total, gather_at_end=True)
+                torch.cuda.synchronize()
+    else:
+        for i in range(args.prewarm):
+            step(i)
+            if i % 4 == 3:
+                torch.cuda.synchronize()
     if pipelined and args.warmup > 0:              # the W warm-up steps run the timed loop's own code path (second stream included)
         from ocn_amd.pipeline import pipelined_shard_loop
         with torch.no_grad():
@@ -523,7 +534,7 @@ def main():
     # the overlap is measured against.  Reported next to the timed region's own figures, never instead of them.
     timer1, dt1 = None, None
     overlapped = pipelined and "HIP stream" in pattern_main
-    if overlapped and not args.no_stage_timers:
+    if overlapped and not args.no_stage_timers and not args.no_one_stream_leg:
         n1 = min(args.steps, 64)
         timer1 = StageTimer(pool=48 * (n1 // max(args.timer_every or max(1, n1 // 8), 1) + 2))
         dt1, _, _ = timed_loop(n1, timer1, overlap=False)

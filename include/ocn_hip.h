@@ -218,10 +218,13 @@ int ocn_cn_walk_group(const int64_t* rowptrA, const int32_t* colA, const int64_t
  * non-zero; for innerprod == 0 (a fresh model) nip is 0 whatever the scale, and zeroed scalars suffice;
  * `valued` != 0 for walk-count cn2.
  * cn7 (model.py:3114-3126, 3186-3209): w1 = 1/S1, `sum_fill` where S1 < 2; cn2 raw ->
- * {w1, 0, 1, 0}. */
+ * {w1, 0, 1, 0}.  diag1 / diag2 (or NULL = ones): the Chebyshev diagonals diag(T_k(linspace(-1, 1, N))) of
+ * evaluate_polynomial (model.py:2958-3019) that the reference multiplies the normalised cn1 (:3141-3165) and the raw cn2
+ * (:3186-3209) by — one fp32 product per entry: {w1 * diag1[c], 0, diag2[c], 0}.  The reference hard-wires k = 0. */
 int ocn_cn_weights_cn5(uint64_t* hist, int64_t N, const float* innerprod, int32_t* scalars,
                        int32_t valued, const float* s2_exact /* or NULL: closed form from the counts */, void* stream);
-int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream);
+int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, const float* diag1 /* [N] or NULL */,
+                       const float* diag2 /* [N] or NULL */, void* stream);
 
 /* scalars[0] (zero before the first call of a batch; idempotent afterwards) = the batch's scale statistic of
  * model.py:2370-2375: 0 = empty union, -1 = no column with S1 >= 2, else min{S1 >= 2} - INT_MAX - 1. */
@@ -303,6 +306,15 @@ int ocn_cn_gather3(const int64_t* rowptrA, const int32_t* colA, const int64_t* s
  *   dh[i] += g3[e] (.) h[j],  dh[j] += g3[e] (.) h[i].
  * dh [N][H] must be initialised by the caller (zeros); fp32 atomic adds (summation order varies
  * between runs).  H in {16..512, power of two}. */
+/* Backward of ocn_cn_gather3 with respect to h (cn6 under autograd, model.py:2535-2951): dh[k] += w1 g1[e] + w2 g2[e] + w3 g3[e]
+ * over the union entries — the weights formed as the forward forms them —, dh[i] += g4[e] * h[j], dh[j] += g4[e] * h[i];
+ * fp32 atomics into dh (zeroed by the caller). */
+int ocn_cn_gather3_backward(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
+                            const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flagsA,
+                            const uint8_t* flagsB, const float* weightsA, const float* weightsB, const float* nip,
+                            const float* h, int32_t H, const float* g1, const float* g2, const float* g3,
+                            const float* g4, float* dh, void* stream);
+
 int ocn_cn_gather_backward(const int64_t* rowptrA, const int32_t* colA,
                            const int64_t* src, const int64_t* dst, const int64_t* order, int64_t B,
                            const int64_t* off, const uint8_t* flags, const int32_t* wc,

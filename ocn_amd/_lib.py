@@ -47,7 +47,7 @@ SIGNATURES = {
     "ocn_cn5_column_stats": (c_int32, [_P, c_int64, _P, _P]),
     "ocn_cn_colsum_workspace_bytes": (c_int64, [c_int64, c_int64]),
     "ocn_cn_colsum_exact": (c_int32, [_P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, _P, _P]),
-    "ocn_cn_weights_cn7": (c_int32, [_P, c_int64, c_float, _P]),
+    "ocn_cn_weights_cn7": (c_int32, [_P, c_int64, c_float, _P, _P, _P]),
     "ocn_cn_gather": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P, _P,
                                 _P, _P, _P, _P, _P]),
     "ocn_gather_schedule": (c_int32, [_P, c_int64, _P, _P]),
@@ -57,6 +57,7 @@ SIGNATURES = {
     "ocn_wgrad": (c_int32, [_P, c_int64, _P, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P]),
     "ocn_cn_weights_cn6": (c_int32, [_P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "ocn_cn_gather3": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),
+    "ocn_cn_gather3_backward": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P, _P]),
     "ocn_cn_gather_backward": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, _P, _P, _P, _P, _P]),
     "ocn_cn_gather_backward_det_workspace_bytes": (c_int64, [c_int64, c_int64, c_int64]),
     "ocn_cn_gather_backward_det": (c_int32, [_P, _P, _P, _P, c_int64, _P, _P, _P, c_int64, _P, _P, c_int64, c_int32, _P, _P, _P, _P,
@@ -122,6 +123,9 @@ def build_flags(extra_flags=()):
             # the reference's CPU kernels round the product and the sum separately; HIP's __fmul_rn /
             # __fadd_rn are plain * and + and would be contracted into FMAs under the default mode
             "-ffp-contract=off",
+            # every unit's compile command is recorded in the library (.GCC.command.line): a build with an experiment macro
+            # (-DOCN_X_*: timing ablations, several of which compute wrong results) can be told from the product build
+            "-frecord-command-line",
             f"-I{INCLUDE}", f"-I{CSRC}", *extra_flags]
 
 

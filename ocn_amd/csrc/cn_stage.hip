@@ -686,16 +686,21 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn6_column_weights(u64* __restrict_
   }
 }
 
+// d1 / d2 (or NULL = all ones): the diagonals diag(T_k(linspace(-1, 1, N))) the reference multiplies the normalised cn1 and
+// the raw cn2 by (evaluate_polynomial, model.py:2995-3019; spspmm with the diagonal at :3141-3165 and :3186-3209 — one fp32
+// product per entry).  The drivers hard-wire k = 0 (T0 = 1, the --polyfirst / --polysecond flags are parsed and ignored, Q4).
 __global__ __launch_bounds__(OCN_BLOCK) void cn7_column_weights(u64* __restrict__ hist, i64 N,
-                                                                float sum_fill) {
+                                                                float sum_fill, const float* __restrict__ d1,
+                                                                const float* __restrict__ d2) {
   float4* wout = reinterpret_cast<float4*>(hist);
   for (i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x; c < N; c += (i64)gridDim.x * blockDim.x) {
     const u64 pk = hist[2 * c];
     if (pk == 0) continue;
     const int n1 = hf_n1(pk);
     const float inv1 = n1 >= 2 ? 1.0f / (float)n1 : sum_fill;          // model.py:3116-3120
-    // x T0 == 1 (model.py:2958, 3141-3165); cn2 raw (Q5, :3186-3209): t = 0, inv2 = 1
-    wout[c] = make_float4(__fmul_rn(inv1, 1.0f), 0.0f, 1.0f, 0.0f);
+    // cn1: ncn1 x T_k1 (model.py:3141-3165); cn2 raw (Q5) x T_k2 (:3186-3209): t = 0, "inv2" = the diagonal's entry, so that
+    // an entry's weight (c - 0) * inv2 is the one product c * T_k2 the reference forms
+    wout[c] = make_float4(__fmul_rn(inv1, d1 ? d1[c] : 1.0f), 0.0f, d2 ? d2[c] : 1.0f, 0.0f);
   }
 }
 
@@ -1448,6 +1453,76 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_scatter_kernel(
   }
 }
 
+// cn6: the transposed pooling of cn_gather3_kernel, dh[k] += w1 g1[e] + w2 g2[e] + w3 g3[e] over the union entries with the
+// weights formed exactly as the forward forms them, and the Hadamard term's two ends from g4.  fp32 atomics.
+template <int LPE, int NV>
+__global__ __launch_bounds__(OCN_BLOCK) void cn_scatter3_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
+    const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
+    const i64* __restrict__ off, const uint8_t* __restrict__ flagsA, const uint8_t* __restrict__ flagsB,
+    const float4* __restrict__ wA, const float4* __restrict__ wB, const float* __restrict__ nip_p,
+    const float* __restrict__ h, int H, const float* __restrict__ g1, const float* __restrict__ g2,
+    const float* __restrict__ g3, const float* __restrict__ g4, float* __restrict__ dh) {
+  constexpr int GPW = OCN_WAVE / LPE;
+  const int lane = threadIdx.x & 63;
+  const int gl = lane % LPE;
+  const int gbase = lane - gl;
+  const i64 slot = ((i64)blockIdx.x * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
+  if (slot >= B) return;
+  const i64 e = order ? order[slot] : slot;
+  const i64 i = src[e], j = dst[e];
+  const i64 a0 = rowptrA[i], da = rowptrA[i + 1] - a0;
+  const i64 base = off[e];
+  const float nip = nip_p[0];
+  const i64 rowq = H >> 2;
+  const float4* h4 = reinterpret_cast<const float4*>(h);
+  float4 v1[NV], v2[NV], v3[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    v1[v] = reinterpret_cast<const float4*>(g1)[e * rowq + gl + v * LPE];
+    v2[v] = reinterpret_cast<const float4*>(g2)[e * rowq + gl + v * LPE];
+    v3[v] = reinterpret_cast<const float4*>(g3)[e * rowq + gl + v * LPE];
+  }
+  for (i64 p0 = 0; p0 < da; p0 += LPE) {
+    const i64 p = p0 + gl;
+    int32_t k = 0;
+    unsigned fa = 0, fb = 0;
+    if (p < da) { k = colA[a0 + p]; fa = flagsA[base + p]; fb = flagsB[base + p] & OCN_F_CN1; }
+    float w1 = 0.f, w2 = 0.f, w3 = 0.f;
+    if (fa | fb) {                           // (the weights of cn_gather3_kernel, term for term)
+      const float4 a = wA[k];
+      const float inv3 = wB[k].x;
+      const float tt = (fa & OCN_F_CN1) ? a.y : 0.f;
+      w1 = (fa & OCN_F_CN1) ? a.x : 0.f;
+      w2 = __fmul_rn(__fsub_rn((fa & OCN_F_CN2) ? 1.0f : 0.f, tt), a.z);
+      w3 = __fmul_rn(__fsub_rn(__fsub_rn(fb ? 1.0f : 0.f, tt), __fmul_rn(nip, w2)), inv3);
+    }
+    unsigned long long m = __ballot((w1 != 0.f) | (w2 != 0.f) | (w3 != 0.f));
+    if (LPE < 64) m = (m >> gbase) & ((1ull << (LPE & 63)) - 1ull);
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int32_t kk = __shfl(k, gbase + b, OCN_WAVE);
+      const float a = __shfl(w1, gbase + b, OCN_WAVE), bb = __shfl(w2, gbase + b, OCN_WAVE), cc = __shfl(w3, gbase + b, OCN_WAVE);
+      float* row = dh + (i64)kk * H + 4 * gl;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        float4 c;
+        c.x = a * v1[v].x + bb * v2[v].x + cc * v3[v].x; c.y = a * v1[v].y + bb * v2[v].y + cc * v3[v].y;
+        c.z = a * v1[v].z + bb * v2[v].z + cc * v3[v].z; c.w = a * v1[v].w + bb * v2[v].w + cc * v3[v].w;
+        atomic_add4(row + 4 * v * LPE, c);
+      }
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const float4 g = reinterpret_cast<const float4*>(g4)[e * rowq + gl + v * LPE];
+    const float4 hi = h4[i * rowq + gl + v * LPE], hj = h4[j * rowq + gl + v * LPE];
+    atomic_add4(dh + i * H + 4 * (gl + v * LPE), make_float4(g.x * hj.x, g.y * hj.y, g.z * hj.z, g.w * hj.w));
+    atomic_add4(dh + j * H + 4 * (gl + v * LPE), make_float4(g.x * hi.x, g.y * hi.y, g.z * hi.z, g.w * hi.w));
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
@@ -1643,12 +1718,12 @@ int ocn_cn_weights_cn6(uint64_t* histA, uint64_t* histB, int64_t N, const float*
   return launch_status();
 }
 
-int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, void* stream) {
+int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, const float* diag1, const float* diag2, void* stream) {
   if (N < 0 || (N > 0 && !hist)) return OCN_EINVAL;
   if (N == 0) return 0;
   const int grid = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
   hipLaunchKernelGGL(cn7_column_weights, dim3(grid), dim3(OCN_BLOCK), 0, (hipStream_t)stream,
-                     (u64*)hist, (i64)N, sum_fill);
+                     (u64*)hist, (i64)N, sum_fill, diag1, diag2);
   return launch_status();
 }
 
@@ -1783,6 +1858,36 @@ int ocn_cn_gather_backward(const int64_t* rowptrA, const int32_t* colA, const in
     case 128: LAUNCH_SCATTER(32, 1); break;
     case 256: LAUNCH_SCATTER(64, 1); break;
     case 512: LAUNCH_SCATTER(64, 2); break;
+    default: return OCN_EINVAL;
+  }
+  return launch_status();
+}
+
+#define LAUNCH_SCATTER3(LPE, NV)                                                                    \
+  do {                                                                                              \
+    const i64 epb = (i64)OCN_WPB * (OCN_WAVE / (LPE));                                              \
+    hipLaunchKernelGGL((cn_scatter3_kernel<LPE, NV>), dim3((unsigned)((B + epb - 1) / epb)),        \
+                       dim3(OCN_BLOCK), 0, (hipStream_t)stream, (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, \
+                       (const i64*)order, (i64)B, (const i64*)off, flagsA, flagsB, (const float4*)weightsA,                 \
+                       (const float4*)weightsB, nip, h, (int)H, g1, g2, g3, g4, dh);                                     \
+  } while (0)
+
+int ocn_cn_gather3_backward(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, const int64_t* dst,
+                            const int64_t* order, int64_t B, const int64_t* off, const uint8_t* flagsA,
+                            const uint8_t* flagsB, const float* weightsA, const float* weightsB, const float* nip,
+                            const float* h, int32_t H, const float* g1, const float* g2, const float* g3,
+                            const float* g4, float* dh, void* stream) {
+  if (B < 0 || H <= 0) return OCN_EINVAL;
+  if (B == 0) return 0;
+  if (!rowptrA || !src || !dst || !off || !flagsA || !flagsB || !weightsA || !weightsB || !nip || !h || !g1 || !g2 || !g3 || !g4 || !dh)
+    return OCN_EINVAL;
+  switch (H) {
+    case 16:  LAUNCH_SCATTER3(4, 1); break;
+    case 32:  LAUNCH_SCATTER3(8, 1); break;
+    case 64:  LAUNCH_SCATTER3(16, 1); break;
+    case 128: LAUNCH_SCATTER3(32, 1); break;
+    case 256: LAUNCH_SCATTER3(64, 1); break;
+    case 512: LAUNCH_SCATTER3(64, 2); break;
     default: return OCN_EINVAL;
   }
   return launch_status();

@@ -12,7 +12,7 @@ the parameters.
 """
 from __future__ import annotations
 
-from typing import Final, Iterable
+from typing import Final, Iterable, Optional
 
 import torch
 import torch.nn as nn
@@ -116,6 +116,62 @@ class _PoolFn(torch.autograd.Function):
     def backward(ctx, g1, g2, g3):
         h, w = ctx.saved_tensors
         return ctx.st.gather_backward(w, h, g1, g2, g3), None, None
+
+
+class _PoolFn3(torch.autograd.Function):
+    """cn6's (xcn1, xcn2, xcn3, x_i ⊙ x_j) = pooling(h): as ``_PoolFn`` with the third pool (model.py:2933)."""
+
+    @staticmethod
+    def forward(ctx, h, st, wa, wb, nip):
+        ctx.st = st
+        ctx.save_for_backward(h, wa, wb, nip)
+        return st.gather(wa, wb, nip, h)
+
+    @staticmethod
+    def backward(ctx, g1, g2, g3, g4):
+        h, wa, wb, nip = ctx.saved_tensors
+        return ctx.st.gather_backward(wa, wb, nip, h, g1, g2, g3, g4), None, None, None, None
+
+
+# Chebyshev bases of cn7 (model.py:2958-3019).  T_k as the reference writes them — the same terms in the same order, each
+# power by ``**`` — because the diagonal is fp32 data of the forward: (coefficient, power) pairs added left to right.
+_CHEB_TERMS = (
+    ((1, 0),),
+    ((1, 1),),
+    ((2, 2), (-1, 0)),
+    ((4, 3), (-3, 1)),
+    ((8, 4), (-8, 2), (1, 0)),
+    ((16, 5), (-20, 3), (5, 1)),
+    ((32, 6), (-48, 4), (18, 2), (-1, 0)),
+    ((64, 7), (-112, 5), (56, 3), (-7, 1)),
+    ((128, 8), (-256, 6), (160, 4), (-32, 2), (1, 0)),
+    ((256, 9), (-576, 7), (432, 5), (-120, 3), (9, 1)),
+    ((512, 10), (-1280, 8), (1120, 6), (-400, 4), (50, 2), (-1, 0)),
+)
+_cheb_cache: dict = {}
+
+
+def chebyshev_diag(n: int, k: int, device) -> Optional[Tensor]:
+    """diag(T_k(linspace(-1, 1, n))) as float32 [n] on ``device`` — what ``evaluate_polynomial(n, k)`` (model.py:2995-3019)
+    puts on the diagonal.  Evaluated with torch on the CPU exactly as the reference evaluates it (torch.linspace, ``x ** p``,
+    the terms left to right) and uploaded once per (n, k, device); None for k = 0 (T0 = 1: no multiply at all)."""
+    if k < 0 or k >= len(_CHEB_TERMS):
+        raise ValueError(f"Invalid poly_index. Must be between 0 and {len(_CHEB_TERMS) - 1}.")      # model.py:2997-2998
+    if k == 0:
+        return None
+    key = (int(n), int(k), str(device))
+    d = _cheb_cache.get(key)
+    if d is None:
+        x = torch.linspace(-1, 1, int(n))                                  # model.py:3001 (CPU, as the reference)
+        acc = None
+        for coef, p in _CHEB_TERMS[k]:
+            a = abs(coef)
+            term = a if p == 0 else ((x if a == 1 else a * x) if p == 1 else a * x ** p)
+            acc = (term if coef > 0 else -term) if acc is None else (acc + term if coef > 0 else acc - term)
+        if len(_cheb_cache) > 32:
+            _cheb_cache.clear()
+        d = _cheb_cache[key] = acc.to(torch.float32).to(device).contiguous()
+    return d
 
 
 # ------------------------------------------------------------------------------------------
@@ -961,6 +1017,11 @@ class CNLinkPredictorbaselearn(_CNPredictorBase):
     twice, Chebyshev diagonal hard-wired to T0 = identity, raw cn2; same heads."""
     _xcn2_on_union = False
     _weights_need_args = True
+    # Chebyshev basis index of the cn1 / cn2 branch (model.py:3141, 3186: ``evaluate_polynomial(num_cols, 0)`` — the reference
+    # hard-wires 0 = T0 = identity, its --polyfirst / --polysecond flags are parsed and never read, SURVEY Q4).  Plain
+    # attributes, 0 by default: set them on the instance to evaluate the T1 .. T10 variants the reference file defines.
+    polyfirst: int = 0
+    polysecond: int = 0
 
     def multidomainforward(self, x, adj, cn1, cn2, tar_ei, args, filled1: bool = False,
                            cndropprobs: Iterable[float] = []):
@@ -970,7 +1031,9 @@ class CNLinkPredictorbaselearn(_CNPredictorBase):
         return self._heads(x, xcn1, xcn2, xij, getattr(st, "cls", None))
 
     def _weights(self, st, args):
-        return st.weights_cn7(float(args.sum))
+        dev = st.hist.device
+        return st.weights_cn7(float(args.sum), chebyshev_diag(st.N, int(self.polyfirst), dev),
+                              chebyshev_diag(st.N, int(self.polysecond), dev))
 
     def _rowsum(self, st, x):
         """A·h, once per (embeddings, adjacency): cn7's cn2 weights are exactly 1 (raw cn2, model.py:3186-3209), so a
@@ -979,8 +1042,8 @@ class CNLinkPredictorbaselearn(_CNPredictorBase):
         summing ~500 embedding rows again for each of the source's candidates (ocn_hip.h, ocn_cn_gather `rowsum`).  Only
         where it can pay: pattern route, A² at least half full."""
         adj, t2 = st.adj, getattr(st, "t2", None)
-        if not ops.share_full_rows or st.walk or t2 is None or not x.is_cuda or x.dim() != 2:
-            return None
+        if not ops.share_full_rows or st.walk or t2 is None or not x.is_cuda or x.dim() != 2 or int(self.polysecond) != 0:
+            return None                        # (a non-trivial basis weights the cn2 entries: the row sum is not their pool)
         n = adj.size(0)
         if t2.nnz() * 2 < n * n or adj.size(1) != x.shape[0] or n != x.shape[0]:
             return None
@@ -1024,14 +1087,26 @@ class CNLinkPredictor3hopCNs(_CNPredictorBase):
 
     def multidomainforward(self, x, adj, cn1, cn2, cn3, tar_ei, args=None, cndropprobs: Iterable[float] = []):
         from .utils import fuse3
-        if self.training or (torch.is_grad_enabled() and x.requires_grad):
-            raise NotImplementedError("cn6 is forward-only here: call .eval() and score under torch.no_grad()")
+        if self.training:
+            raise NotImplementedError("cn6 in training mode updates the one `innerprod` buffer three times per call with three "
+                                      "different quantities (model.py:2527-2533, 2636, 2817, 2842) and is reached by no driver: "
+                                      "call .eval(); gradients with respect to x and the head parameters flow in eval mode")
         st = fuse3(cn1, cn2, cn3, tar_ei)
         if self._sharded:
             from .dist import allreduce_hist
             allreduce_hist(st.a.hist, self._shard_group, valued=False)
             allreduce_hist(st.b.hist, self._shard_group, valued=False)
         wa, wb, nip = st.weights(self.innerprod, sharded=self._sharded)
+        if torch.is_grad_enabled():
+            # autograd on (row f3): the pooling through _PoolFn3 (its transpose is ocn_cn_gather3_backward), the
+            # heads through the modules / the MFMA Linear under autograd, as cn5 / cn7 do
+            x = x.contiguous()
+            xcn1, xcn2, xcn3, xij = (_PoolFn3.apply(x, st, wa, wb, nip) if x.requires_grad else st.gather(wa, wb, nip, x))
+            alpha = torch.sigmoid(self.alpha).cumprod(-1)
+            run = _seq_train if (xij.is_cuda and ops.train_linear) else (lambda seq, t: seq(t))
+            z = (alpha[0] * run(self.xcn1lin, xcn1) + alpha[1] * run(self.xcn2lin, xcn2)
+                 + alpha[2] * run(self.xcn3lin, xcn3) + self.beta * run(self.xijlin, xij))
+            return run(self.lin, z)
         xcn1, xcn2, xcn3, xij = st.gather(wa, wb, nip, x.contiguous())
         with torch.no_grad():
             alpha = torch.sigmoid(self.alpha).cumprod(-1)

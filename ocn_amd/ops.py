@@ -437,9 +437,13 @@ def cn_weights_cn5(hist: Tensor, innerprod: Tensor, valued: bool = False, wsd=No
 
 
 @_on_device
-def cn_weights_cn7(hist: Tensor, sum_fill: float) -> Tensor:
+def cn_weights_cn7(hist: Tensor, sum_fill: float, diag1: Optional[Tensor] = None, diag2: Optional[Tensor] = None) -> Tensor:
+    """``diag1`` / ``diag2``: the Chebyshev diagonals of the cn1 / cn2 branch (float32 [N]; None = T0 = ones)."""
     _req(hist, torch.int64, "hist", 2)
-    check(_lib.lib().ocn_cn_weights_cn7(ptr(hist), hist.shape[0], float(sum_fill), stream_ptr()),
+    for d, nm in ((diag1, "diag1"), (diag2, "diag2")):
+        if d is not None and _req(d, torch.float32, nm, 1).numel() != hist.shape[0]:
+            raise ValueError(f"{nm}: one entry per column")
+    check(_lib.lib().ocn_cn_weights_cn7(ptr(hist), hist.shape[0], float(sum_fill), ptr(diag1), ptr(diag2), stream_ptr()),
           "ocn_cn_weights_cn7")
     _mark("cn_weights")
     return hist.view(torch.float32)
@@ -547,6 +551,23 @@ def cn_gather3(rowptrA, colA, src, dst, off, flagsA, flagsB, wA: Tensor, wB: Ten
                                     ptr(out[2]), ptr(out[3]), stream_ptr()), "ocn_cn_gather3")
     _mark("cn_gather")
     return out[0], out[1], out[2], out[3]
+
+
+@_on_device
+def cn_gather3_backward(rowptrA, colA, src, dst, off, flagsA, flagsB, wA: Tensor, wB: Tensor, nip: Tensor, h: Tensor,
+                        g1: Tensor, g2: Tensor, g3: Tensor, g4: Tensor, order: Optional[Tensor] = None) -> Tensor:
+    """Gradient of cn6's (xcn1, xcn2, xcn3, xij) with respect to h (ocn_hip.h: ocn_cn_gather3_backward; fp32 atomics)."""
+    B, H = src.numel(), h.shape[1]
+    for t, nm in ((g1, "g1"), (g2, "g2"), (g3, "g3"), (g4, "g4")):
+        if _req(t, torch.float32, nm, 2).shape != (B, H):
+            raise ValueError(f"{nm}: expected [{B}, {H}]")
+    if H not in LN_WIDTHS:
+        raise NotImplementedError(f"cn6 pooling backward supports hidden widths {LN_WIDTHS}, got {H}")
+    dh = torch.zeros_like(h)
+    check(_lib.lib().ocn_cn_gather3_backward(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flagsA),
+                                             ptr(flagsB), ptr(wA), ptr(wB), ptr(nip), ptr(h), H, ptr(g1), ptr(g2), ptr(g3), ptr(g4),
+                                             ptr(dh), stream_ptr()), "ocn_cn_gather3_backward")
+    return dh
 
 
 @_on_device

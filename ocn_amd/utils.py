@@ -157,10 +157,10 @@ class CNState:
                 s2 = run(None)
         return ops.cn_weights_cn5(self.hist, innerprod, valued=self.walk, wsd=self.ws, s2_exact=s2, scal=scal)
 
-    def weights_cn7(self, sum_fill: float) -> Tensor:
+    def weights_cn7(self, sum_fill: float, diag1: Optional[Tensor] = None, diag2: Optional[Tensor] = None) -> Tensor:
         assert self._hist_live, "histogram already consumed"
         self._hist_live = False
-        return ops.cn_weights_cn7(self.hist, sum_fill)
+        return ops.cn_weights_cn7(self.hist, sum_fill, diag1, diag2)
 
     def gather(self, weights: Tensor, h: Tensor, order: Optional[Tensor] = None, out_row: Optional[Tensor] = None,
                rowsum: Optional[Tensor] = None):
@@ -280,6 +280,11 @@ class CNState3:
     def gather(self, wa: Tensor, wb: Tensor, nip: Tensor, h: Tensor):
         return ops.cn_gather3(self.adj._rowptr, self.adj._col, self.a.src, self.a.dst, self.a.off, self.a.flags,
                               self.b.flags, wa, wb, nip, h, order=self.a.order)
+
+    def gather_backward(self, wa: Tensor, wb: Tensor, nip: Tensor, h: Tensor, g1, g2, g3, g4) -> Tensor:
+        return ops.cn_gather3_backward(self.adj._rowptr, self.adj._col, self.a.src, self.a.dst, self.a.off, self.a.flags,
+                                       self.b.flags, wa, wb, nip, h, g1.contiguous(), g2.contiguous(), g3.contiguous(),
+                                       g4.contiguous(), order=self.a.order)
 
 
 def _same_edges(a: Tensor, b: Tensor) -> bool:

@@ -388,25 +388,52 @@ def cn6_forward(sd: Dict[str, Tensor], x: Tensor, cn1: SpM, cn2: SpM, cn3: SpM, 
 # ----------------------------------------------------------------------------
 # cn7 = CNLinkPredictorbaselearn.multidomainforward, eval (model.py:3102-3226)
 # ----------------------------------------------------------------------------
-def cn7_pool(x: Tensor, cn1: SpM, cn2: SpM, sum_fill: float):
+# model.py:2958-2990: the Chebyshev polynomials T0 .. T10, written as the reference writes them (fp32: the order of the
+# terms and the ``**`` powers are part of the value)
+POLYNOMIALS = [
+    lambda x: torch.ones_like(x),
+    lambda x: x,
+    lambda x: 2 * x**2 - 1,
+    lambda x: 4 * x**3 - 3 * x,
+    lambda x: 8 * x**4 - 8 * x**2 + 1,
+    lambda x: 16 * x**5 - 20 * x**3 + 5 * x,
+    lambda x: 32 * x**6 - 48 * x**4 + 18 * x**2 - 1,
+    lambda x: 64 * x**7 - 112 * x**5 + 56 * x**3 - 7 * x,
+    lambda x: 128 * x**8 - 256 * x**6 + 160 * x**4 - 32 * x**2 + 1,
+    lambda x: 256 * x**9 - 576 * x**7 + 432 * x**5 - 120 * x**3 + 9 * x,
+    lambda x: 512 * x**10 - 1280 * x**8 + 1120 * x**6 - 400 * x**4 + 50 * x**2 - 1,
+]
+
+
+def evaluate_polynomial(n: int, poly_index: int) -> Tensor:
+    """model.py:2995-3019: the diagonal of ``diag(T_k(linspace(-1, 1, n)))`` (the reference wraps it in an n x n
+    SparseTensor; only the diagonal carries data)."""
+    if poly_index < 0 or poly_index >= len(POLYNOMIALS):
+        raise ValueError(f"Invalid poly_index. Must be between 0 and {len(POLYNOMIALS)-1}.")
+    return POLYNOMIALS[poly_index](torch.linspace(-1, 1, n))
+
+
+def cn7_pool(x: Tensor, cn1: SpM, cn2: SpM, sum_fill: float, polyfirst: int = 0, polysecond: int = 0):
+    """``polyfirst`` / ``polysecond``: the index the reference passes to evaluate_polynomial at :3141 / :3186 — the literal 0
+    there (T0 = identity; the drivers' --polyfirst / --polysecond flags are never read)."""
     S1 = col_sum(cn1)                                   # :3114
     S1[S1 == 0] = 1
     inv1 = 1 / S1
     inv1[~(S1 != 1)] = sum_fill                         # :3120 (Q2 with args.sum)
-    # × diag(T0(linspace(-1,1,N))) with T0 ≡ 1 (model.py:2958-2959, 3141-3165): one product
-    # per entry, value·1.0 — restated as the explicit multiply.
-    t0 = torch.ones(cn1.n_cols)
-    ncn1 = SpM(cn1.row, cn1.col, (inv1[cn1.col] * cn1.val) * t0[cn1.col], cn1.n_rows, cn1.n_cols)
-    # normalized_cn2 is computed and discarded (:3168-3180, Q5); raw cn2 × identity is used.
-    rcn2 = SpM(cn2.row, cn2.col, cn2.val * t0[cn2.col], cn2.n_rows, cn2.n_cols)
+    # × diag(T_k(linspace(-1,1,N))) (model.py:3141-3165): spspmm with a diagonal = one product per entry
+    d1 = evaluate_polynomial(cn1.n_cols, polyfirst)
+    ncn1 = SpM(cn1.row, cn1.col, (inv1[cn1.col] * cn1.val) * d1[cn1.col], cn1.n_rows, cn1.n_cols)
+    # normalized_cn2 is computed and discarded (:3168-3180, Q5); the RAW cn2 × the second diagonal is used (:3186-3209).
+    d2 = evaluate_polynomial(cn2.n_cols, polysecond)
+    rcn2 = SpM(cn2.row, cn2.col, cn2.val * d2[cn2.col], cn2.n_rows, cn2.n_cols)
     xcn1 = spmm_add(ncn1, x)                            # :3213
     xcn2 = spmm_add(rcn2, x)                            # :3214
     return xcn1, xcn2, dict(S1=S1, inv1=inv1, ncn1=ncn1)
 
 
 def cn7_forward(sd, x, cn1, cn2, tar_ei, sum_fill: float, ln=False, tailact=False,
-                twolayerlin=False) -> Tensor:
-    xcn1, xcn2, _ = cn7_pool(x, cn1, cn2, sum_fill)
+                twolayerlin=False, polyfirst: int = 0, polysecond: int = 0) -> Tensor:
+    xcn1, xcn2, _ = cn7_pool(x, cn1, cn2, sum_fill, polyfirst, polysecond)
     return _heads(sd, x, xcn1, xcn2, tar_ei, ln, tailact, twolayerlin)
 
 

@@ -278,3 +278,21 @@ def test_overlapped_steps_host_order_without_a_gpu():
     for it in range(5):
         assert log.index(("pre", it)) < log.index(("B", it)) < log.index(("post", it))
     assert list(overlapped_steps(begin, finish, 0, overlap=False)) == []
+
+
+def test_the_shipped_library_was_built_without_experiment_macros(hiplib):
+    """the kernels carry ~30 `OCN_X_*` timing-experiment switches, several of which give wrong results when
+    defined.  The product build never defines one: `_lib.build_flags()` holds none, the library records the compile command of
+    every translation unit (-frecord-command-line -> .GCC.command.line) and none of them names one, and no `ocn_debug_*` entry
+    (they only exist under those switches) is exported."""
+    import re
+    from ocn_amd import _lib
+    assert not any("OCN_X_" in f for f in _lib.build_flags())
+    blob = open(_lib.LIB_PATH, "rb").read()
+    cmds = re.findall(rb"[^\x00]*-frecord-command-line[^\x00]*", blob)
+    units = {os.path.basename(s) for s in _lib.sources()}
+    seen = {u for u in units for c in cmds if u.encode() in c}
+    assert seen == units, f"compile commands recorded for {sorted(seen)} of {sorted(units)}"
+    assert all(b"-ffp-contract=off" in c for c in cmds) and sum(b"gfx950" in c for c in cmds) >= len(units)
+    assert b"OCN_X_" not in blob
+    assert b"ocn_debug_" not in blob

@@ -274,3 +274,34 @@ def test_block_route_known_answers_on_a_path():
     a2, fq = O.adj2_by_block(adj, block_size=bs), O.adj2_by_block(adj, block_size=bs, fold_quirk=True)
     assert set(zip(a2.row.tolist(), a2.col.tolist())) == full
     assert set(zip(fq.row.tolist(), fq.col.tolist())) == fold
+
+
+def test_chebyshev_diagonals_of_cn7():
+    """model.py:2958-3019: T_k(linspace(-1, 1, n)) — the oracle's restatement against numpy's Chebyshev evaluation (fp64, so
+    to rounding), T0 = ones, the index check's error, and k = 0 leaving cn7's pools untouched."""
+    import numpy as np
+    from numpy.polynomial import chebyshev as C
+    for n in (1, 2, 7, 1001):
+        xs = np.linspace(-1, 1, n)
+        for k in range(11):
+            d = O.evaluate_polynomial(n, k)
+            assert d.dtype == torch.float32 and d.shape == (n,)
+            assert np.abs(d.numpy() - C.chebval(xs, [0] * k + [1])).max() <= 2e-4      # (|T_10| terms reach 1280: fp32 cancellation)
+    assert torch.equal(O.evaluate_polynomial(9, 0), torch.ones(9))
+    for bad in (-1, 11):
+        try:
+            O.evaluate_polynomial(5, bad)
+        except ValueError:
+            continue
+        raise AssertionError("poly_index outside 0..10 must raise")
+    oadj = O.to_symmetric(O.from_edge_index(torch.tensor([[0, 1, 2, 0], [1, 2, 3, 2]]), 4))
+    e = torch.tensor([[0, 1, 0], [1, 3, 3]])
+    cn1, cn2 = O.adjoverlap(oadj, oadj, e), O.adjoverlap(oadj, O.adj2_sparse(oadj), e)
+    x = torch.arange(8, dtype=torch.float32).reshape(4, 2)
+    a = O.cn7_pool(x, cn1, cn2, 1.0)
+    b = O.cn7_pool(x, cn1, cn2, 1.0, polyfirst=0, polysecond=0)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    # T1 on 4 columns = linspace(-1, 1, 4): the cn2 pool of edge (0, 1) = columns {1, 2} -> (-1/3) h[1] + (1/3) h[2]
+    c = O.cn7_pool(x, cn1, cn2, 1.0, polysecond=1)
+    d = torch.linspace(-1, 1, 4)
+    assert torch.equal(c[1][0], (d[1] * x[1]) + (d[2] * x[2]))

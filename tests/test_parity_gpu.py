@@ -1632,3 +1632,106 @@ def test_cn7_full_rows_share_the_row_sum(hiplib, monkeypatch, H, B, lnnn):
         oref = O.cn7_forward({k: v.detach().cpu() for k, v in pred.state_dict().items()}, x.cpu(), O.adjoverlap(oadj, oadj, ec),
                              O.adjoverlap(oadj, O.adj2_sparse(oadj), ec), ec, args.sum, lnnn)
         assert close(got, oref)
+
+
+# ---- row f3: the Chebyshev bases of cn7 and cn6 under autograd ---------------------------------------
+@pytest.mark.parametrize("k1,k2", [(0, 0), (1, 0), (4, 1), (10, 4), (0, 10)])
+@pytest.mark.parametrize("route", ["pattern", "walk"])
+def test_cn7_chebyshev_bases(case, k1, k2, route):
+    """model.py:2958-3019, 3141-3165, 3186-3209: cn1 <- ncn1 * diag(T_k1(linspace(-1, 1, N))), cn2 <- cn2 * diag(T_k2(...)).
+    The reference hard-wires k = 0 (its --polyfirst / --polysecond flags are dead); the predictor exposes the index
+    as `polyfirst` / `polysecond` (default 0).  Pooled vectors bit-equal to the oracle for every basis tried, on both CN routes
+    (the walk route's cn2 values are walk counts: value * T_k2 is still one product), scores within 1e-5."""
+    from ocn_amd.model import chebyshev_diag, predictor_dict
+    from ocn_amd.utils import CNState, adjoverlap, get_cn1_cn2
+    H = 64
+    torch.manual_seed(case.seed + 3)
+    x = torch.randn(case.n, H)
+    e = case.e.to(DEV)
+    if route == "walk":
+        ocn1, ocn2 = O.get_cn1_cn2(case.oadj, case.e)
+        st = CNState(case.adj, None, None, e, walk=True)
+    else:
+        ocn1, ocn2 = case.ocn1, case.ocn2
+        st = CNState(case.adj, case.adj, case.adj2, e)
+    r1, r2, _ = O.cn7_pool(x, ocn1, ocn2, 2.74, polyfirst=k1, polysecond=k2)
+    w = st.weights_cn7(2.74, chebyshev_diag(case.n, k1, DEV), chebyshev_diag(case.n, k2, DEV))
+    g1, g2, _ = st.gather(w, x.to(DEV))
+    assert torch.equal(g1.cpu(), r1) and torch.equal(g2.cpu(), r2)
+    pred = predictor_dict["cn7"](H, H, 1, 3, 0.0, 0.0, True).eval()
+    sd = {k: v.detach().clone() for k, v in pred.state_dict().items()}
+    ref = O.cn7_forward(sd, x, ocn1, ocn2, case.e, 2.74, True, polyfirst=k1, polysecond=k2)
+    pred = pred.to(DEV)
+    assert pred.polyfirst == 0 and pred.polysecond == 0          # the reference's hard-wired basis is the default
+    pred.polyfirst, pred.polysecond = k1, k2
+    handles = get_cn1_cn2(case.adj, e) if route == "walk" else (adjoverlap(case.adj, case.adj, e), adjoverlap(case.adj, case.adj2, e))
+    with torch.no_grad():
+        out = pred(x.to(DEV), case.adj, *handles, e, SimpleNamespace(sum=2.74))
+    tol = 1e-5 if route == "pattern" else 1e-5 * max(1.0, ref.abs().max().item())      # (raw walk-count pools: relative)
+    assert (out.cpu() - ref).abs().max().item() <= tol + 1e-5 * ref.abs().max().item()
+    with pytest.raises(ValueError):
+        chebyshev_diag(case.n, 11, DEV)
+
+
+def test_cn7_chebyshev_basis_switches_the_row_sum_shortcut_off(hiplib):
+    """The dense-graph shortcut copies (A h)[source] for a candidate whose whole source row is cn2 — only valid while every
+    cn2 weight is 1: with a non-trivial second basis the pooling must sum the weighted entries itself."""
+    from ocn_amd import ops
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    n, H, B = 900, 64, 4096
+    oadj = make_graph(n, 300, 850, seed=5, clique_frac=0.2)
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    assert adj2.nnz() * 2 > n * n
+    e = batch(oadj, B, 7)
+    torch.manual_seed(0)
+    x = torch.randn(n, H)
+    pred = predictor_dict["cn7"](H, H, 1, 3, 0.0, 0.0, True).eval()
+    sd = {k: v.detach().clone() for k, v in pred.state_dict().items()}
+    pred = pred.to(DEV)
+    pred.polysecond = 3
+    ed = e.to(DEV)
+    with torch.no_grad():
+        out = pred(x.to(DEV), adj, adjoverlap(adj, adj, ed), adjoverlap(adj, adj2, ed), ed, SimpleNamespace(sum=1.0))
+    oadj2 = O.adj2_sparse(oadj)
+    ref = O.cn7_forward(sd, x, O.adjoverlap(oadj, oadj, e), O.adjoverlap(oadj, oadj2, e), e, 1.0, True, polysecond=3)
+    assert close(out, ref)
+
+
+@pytest.mark.parametrize("ip", [0.0, 0.37])
+def test_cn6_backward_matches_oracle_autograd(case3, ip):
+    """cn6 (model.py:2535-2951) under autograd in eval mode: gradients with respect to the embeddings (the transposed
+    three-pool gather, ocn_cn_gather3_backward) and every used parameter against torch autograd through the oracle."""
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    c = case3
+    H = 32
+    torch.manual_seed(23)
+    x = torch.randn(c.n, H)
+    pred = predictor_dict["cn6"](H, H, 1, 3, 0.0, 0.0, True).eval()
+    with torch.no_grad():
+        pred.alpha.copy_(torch.tensor([0.3, -0.2, 0.9]))
+        pred.innerprod.fill_(ip)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and k != "innerprod") for k, v in pred.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    ref = O.cn6_forward(sd, xr, *c.ocn, c.e, True)
+    wgt = torch.randn(c.B, 1, generator=torch.Generator().manual_seed(1))
+    (ref * wgt).sum().backward()
+    pred = pred.to(DEV)
+    ed = c.e.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    out = pred(xd, c.adj, adjoverlap(c.adj, c.adj, ed), adjoverlap(c.adj, c.adj2, ed), adjoverlap(c.adj, c.adj3, ed), ed, None)
+    assert out.requires_grad and close(out, ref)
+    (out * wgt.to(DEV)).sum().backward()
+    scale = xr.grad.abs().max().item()
+    assert (xd.grad.cpu() - xr.grad).abs().max().item() <= 2e-5 * max(1.0, scale)
+    seen = 0
+    for k, p in pred.named_parameters():
+        if sd[k].grad is None:
+            assert p.grad is None or p.grad.abs().max().item() == 0.0, k
+            continue
+        g = sd[k].grad
+        seen += 1
+        assert (p.grad.cpu() - g).abs().max().item() <= 2e-5 * max(1.0, g.abs().max().item()), k
+    assert seen >= 20 and any(k.startswith("xcn3lin") for k, p in pred.named_parameters() if p.grad is not None)

@@ -142,9 +142,6 @@ def _pool_case(n, avg, mx, B, H, seed, walk=False):
     return adj, product_adj2(adj), e
 
 
-@pytest.mark.parametrize("n,avg,mx,B,H", [(500, 8, 100, 300, 32), (3000, 12, 400, 2048, 64), (20000, 10, 600, 8192, 256),
-                                          (2000, 30, 1500, 4096, 128)], ids=lambda v: str(v))
-@pytest.mark.parametrize("name", ["cn5", "cn7"])
 def _assert_backward_key_lists(adj, adj2, e):
     """Host-side reference of the per-node key lists the deterministic pooling backward accumulates from, checked BEFORE the
     accumulate pass runs (round 3 chased a GPU memory fault in that pass by re-running it; the lists were
@@ -177,6 +174,9 @@ def _assert_backward_key_lists(adj, adj2, e):
     assert torch.equal(col_off2, col_off) and torch.equal(keys2, keys)
 
 
+@pytest.mark.parametrize("n,avg,mx,B,H", [(500, 8, 100, 300, 32), (3000, 12, 400, 2048, 64), (20000, 10, 600, 8192, 256),
+                                          (2000, 30, 1500, 4096, 128)], ids=lambda v: str(v))
+@pytest.mark.parametrize("name", ["cn5", "cn7"])
 def test_pooling_backward_is_deterministic_and_equals_the_atomic_form(hiplib, monkeypatch, name, n, avg, mx, B, H):
     """The node-by-node pooling backward (ocn_cn_gather_backward_det): the same bits on every run, and the atomic kernel's
     result to rounding (fp32 sums in another order)."""
