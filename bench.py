@@ -179,7 +179,8 @@ def build_workload(args, dev, rank, world):
     r, c, _ = adj.coo()
     rc, cc = r.cpu(), c.cpu()
     # `batches` global batches of world x B edges each, seeded 1, 2, ...; rank r owns slice r of each
-    edges = [sample_edges(rc, cc, n, cfg["batch"] * world, seed=1 + b).to(dev) for b in range(max(args.batches, 1))]
+    per_rank = 1 if args.scaling == "strong" else world          # strong scaling: the configuration's one batch, cut over the ranks
+    edges = [sample_edges(rc, cc, n, cfg["batch"] * per_rank, seed=1 + b).to(dev) for b in range(max(args.batches, 1))]
     return dict(cfg=cfg, n=n, adj=adj, adj2=adj2, h=h.contiguous(), pred=pred, edges=edges, enc_s=t_enc, a2_s=t_a2,
                 graph_s=t_graph, nnz=adj.nnz(), nnz2=adj2.nnz() if adj2 is not None else None,
                 max_deg=adj.max_rowcount(), args=SimpleNamespace(sum=cfg["sum"]))
@@ -339,6 +340,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timers", action="store_true")
     ap.add_argument("--no-validate-leg", action="store_true", help="skip the second timed loop with the per-batch id check on")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = `batch` candidates PER RANK of a global batch of N x batch (the default line); strong = the "
+                         "reference's ONE batch (collab: 65 536 edges) cut N ways, north_star's 'partition the edge batch across the GPUs'")
     ap.add_argument("--no-one-stream-leg", action="store_true",
                     help="skip the untimed pass with the streams serialised (the *_one_stream keys): a kernel trace of the command "
                          "then averages over the overlapped loop only, like the line's own stage events")
@@ -662,7 +666,7 @@ def main():
             "metric": f"candidate-edges/sec (CN predictor fwd), ogbl-{args.dataset} shape",
             "value": B_total * args.steps / dt, "unit": "edges/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "dtype_detail": ("sparse stage (intersection, column weights, pooling): f32 products and sums rounded separately, "
                              "integer counts exact; MLP heads: "
                              + ("f16x3-split, f32 accumulate (each f32 product = three f16 MFMAs on hi/lo splits of both operands; the "
@@ -675,8 +679,10 @@ def main():
             "config": {"workload": f"ogbl-{args.dataset}-shaped synthetic graph, {cfg['enc']} {cfg['conv']} x{cfg['layers']} "
                                    f"hiddim={H} predictor={cfg['pred']} built as the reference drivers build it (only cndeg "
                                    f"forwarded: tailact=False, use_xlin=False, beta=1, lnnn={cfg['lnnn']}; head = "
-                                   f"{head_layout(pred)}), CN route={cfg['route']}, batch {cfg['batch']} per GPU, "
-                                   f"{NB} distinct seeded batches in rotation, ids bounds-checked once before the timed "
+                                   f"{head_layout(pred)}), CN route={cfg['route']}, "
+                                   + (f"batch {cfg['batch']} per GPU, " if args.scaling == "weak" else
+                                      f"ONE batch of {cfg['batch']} candidates cut over the {world} GPUs ({B_total // world} per GPU: strong scaling), ")
+                                   + f"{NB} distinct seeded batches in rotation, ids bounds-checked once before the timed "
                                    f"region (BASELINE.json configs[{idx}])",
                        "nodes": wl["n"], "nnz": wl["nnz"], "nnz_A2": wl["nnz2"], "max_deg": wl["max_deg"],
                        "global_batch": B_total, "parallelism": f"edge-shard x{world}", "graph_scale": args.scale,

@@ -281,8 +281,11 @@ int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA,
 /* The pooling's visiting order at H = 256 (a workgroup = four candidates = one group of ocn_cn_flags' gcost): candidates
  * differ 100x in cost and the few with hundreds of rows, met late, end the kernel as stragglers (0.206 -> 0.17 ms at the
  * collab shape).  perm[] = inside each XCD's contiguous eighth of the groups, the groups stable-sorted by descending cost:
- * groups of one source keep one cost and stay neighbours (L2).  n_groups = B / 4, a multiple of 8, at most 8 * 65535. */
-int ocn_gather_schedule(const int32_t* gcost, int64_t n_groups, int32_t* perm, void* stream);
+ * groups of one source keep one cost and stay neighbours (L2).  n_groups = B / 4, a multiple of 8, at most 8 * 65535.
+ * segment > 0 (dividing an eighth): the sort runs inside consecutive segments of that many groups instead of over the whole
+ * eighth — the sources in flight on an XCD then stay within a narrow range of the source order (what their rows' L2
+ * residency depends on) while every segment still starts with its longest jobs; 0 = whole eighths. */
+int ocn_gather_schedule(const int32_t* gcost, int64_t n_groups, int64_t segment, int32_t* perm, void* stream);
 
 /* The 3-hop predictor cn6 (model.py:2535-2951), pattern route.  Two intersection passes over the same
  * candidate batch — (A, A, A²) into flagsA / histA and (A, A³) into flagsB / histB (bit 0 = cn3 entry,

@@ -50,7 +50,7 @@ SIGNATURES = {
     "ocn_cn_weights_cn7": (c_int32, [_P, c_int64, c_float, _P, _P, _P]),
     "ocn_cn_gather": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, c_int32, c_int64, _P, _P, _P, _P, _P,
                                 _P, _P, _P, _P, _P]),
-    "ocn_gather_schedule": (c_int32, [_P, c_int64, _P, _P]),
+    "ocn_gather_schedule": (c_int32, [_P, c_int64, c_int64, _P, _P]),
     "ocn_coo_to_csr_workspace_bytes": (c_int64, [c_int64, c_int64, c_int32, c_int32]),
     "ocn_coo_to_csr": (c_int32, [_P, _P, c_int64, c_int64, c_int64, c_int32, c_int32, _P, _P, _P, _P, _P]),
     "ocn_wgrad_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32]),

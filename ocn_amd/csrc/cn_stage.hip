@@ -1737,12 +1737,15 @@ int ocn_cn_weights_cn7(uint64_t* hist, int64_t N, float sum_fill, const float* d
 // buckets of its contiguous share, the bucket-major table of counts is scanned, and the second pass writes every group
 // to its rank.  Stable: groups of one source (one cost) stay neighbours.
 #define SCHED_BUCKETS 64
-__global__ __launch_bounds__(OCN_BLOCK) void gather_schedule_kernel(const int32_t* __restrict__ gcost, i64 n_groups,
+// `per`: groups per sorted range — an XCD's whole eighth, or a SEGMENT of it (ocn_gather_schedule `segment`): longest first inside
+// segments keeps the sources in flight on an XCD within a narrow id range (their rows then meet in its L2) and still starts
+// every segment with its long jobs.
+__global__ __launch_bounds__(OCN_BLOCK) void gather_schedule_kernel(const int32_t* __restrict__ gcost, i64 per,
                                                                     int32_t* __restrict__ perm) {
   __shared__ unsigned short tc[SCHED_BUCKETS * OCN_BLOCK];
   __shared__ i64 s_scan[2 * OCN_WPB];
   const int t = threadIdx.x;
-  const i64 per = n_groups >> 3, lo = (i64)blockIdx.x * per;                  // (n_groups is a multiple of 8)
+  const i64 lo = (i64)blockIdx.x * per;
   const i64 ipt = (per + OCN_BLOCK - 1) / OCN_BLOCK;                          // groups per thread, contiguous
   for (int b = 0; b < SCHED_BUCKETS; ++b) tc[b * OCN_BLOCK + t] = 0;
   auto bucket = [&](i64 q) -> int {
@@ -1774,11 +1777,13 @@ __global__ __launch_bounds__(OCN_BLOCK) void gather_schedule_kernel(const int32_
   }
 }
 
-int ocn_gather_schedule(const int32_t* gcost, int64_t n_groups, int32_t* perm, void* stream) {
-  if (n_groups < 0 || (n_groups & 7) || (n_groups >> 3) > 65535) return OCN_EINVAL;      // eighths; ranks are 16-bit
+int ocn_gather_schedule(const int32_t* gcost, int64_t n_groups, int64_t segment, int32_t* perm, void* stream) {
+  if (n_groups < 0 || (n_groups & 7) || (n_groups >> 3) > 65535 || segment < 0) return OCN_EINVAL;      // eighths; ranks are 16-bit
   if (n_groups == 0) return 0;
   if (!gcost || !perm) return OCN_EINVAL;
-  hipLaunchKernelGGL(gather_schedule_kernel, dim3(8), dim3(OCN_BLOCK), 0, (hipStream_t)stream, gcost, (i64)n_groups, perm);
+  i64 per = n_groups >> 3;
+  if (segment > 0 && segment < per && per % segment == 0) per = segment;      // (a segment that does not divide the eighth: whole eighths)
+  hipLaunchKernelGGL(gather_schedule_kernel, dim3((unsigned)(n_groups / per)), dim3(OCN_BLOCK), 0, (hipStream_t)stream, gcost, per, perm);
   return launch_status();
 }
 

@@ -152,6 +152,51 @@ def gather_scores(local: Tensor, total: int, group=None, async_op: bool = False)
     return torch.cat([out[r * width: r * width + (e - s)] for r, (s, e) in enumerate(bounds)], dim=0)
 
 
+# ---------------------------------------------------------------------------------------------
+# whole-batch dealing: the partition for the drivers' loops over independent candidate batches
+# ---------------------------------------------------------------------------------------------
+def deal_batches(n_batches: int, world: int, rank: int) -> List[int]:
+    """The batches of a scoring loop that rank ``rank`` owns: round robin.  The reference's test loops
+    (NeighborOverlap_large.py:121-159, NeighborOverlap_large_ppa.py:98-133, NeighborOverlapCitation2.py:227-254) score
+    independent ``PermIterator`` batches; a batch's column normalisation couples only ITS candidates, so a batch
+    kept whole on one GPU needs no exchange at all and its scores equal the single-device ones bit for bit."""
+    return list(range(rank, n_batches, world))
+
+
+def gather_dealt(local: List[Tensor], sizes: List[int], group=None) -> Tensor:
+    """Scores of a dealt scoring loop back in split order.  ``local``: this rank's per-batch score vectors (its
+    ``deal_batches`` share, in that order, each ``[sizes[b]]`` or ``[sizes[b], C]``); ``sizes``: the length of EVERY batch of the
+    loop.  ONE all-gather of the ranks' concatenated scores, padded to the longest share.  Returns ``[sum(sizes), ...]``."""
+    if _solo(group):
+        return torch.cat(local, 0) if local else torch.zeros(0)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    shares = [deal_batches(len(sizes), world, r) for r in range(world)]
+    lens = [sum(sizes[b] for b in sh) for sh in shares]
+    width = max(lens)
+    ref = local[0] if local else None
+    if ref is None:                                     # (a rank without a batch still takes part in the collective)
+        raise ValueError("gather_dealt: every rank needs at least one batch (fewer batches than ranks: score them undealt)")
+    tail = tuple(ref.shape[1:])
+    mine = torch.cat(local, 0)
+    if mine.shape[0] != lens[rank]:
+        raise ValueError("gather_dealt: local scores do not match this rank's share of `sizes`")
+    pad = mine if mine.shape[0] == width else torch.cat([mine, mine.new_zeros((width - mine.shape[0],) + tail)], 0)
+    pad = pad.contiguous()
+    if _host_staged(pad, group) or not pad.is_cuda:
+        parts = [torch.empty(pad.shape, dtype=pad.dtype) for _ in range(world)]
+        dist.all_gather(parts, pad.cpu(), group=group)
+        allsc = torch.stack(parts, 0).to(ref.device)
+    else:
+        allsc = pad.new_empty((world, width) + tail)
+        dist.all_gather_into_tensor(allsc.view((world * width,) + tail), pad, group=group)
+    out, cursor = [None] * len(sizes), [0] * world
+    for b in range(len(sizes)):                         # batch b is rank b % world's next piece
+        r = b % world
+        out[b] = allsc[r, cursor[r]: cursor[r] + sizes[b]]
+        cursor[r] += sizes[b]
+    return torch.cat(out, 0)
+
+
 def sharded_predict(predictor, h: Tensor, adj, adj2, edges: Tensor, args=None, group=None) -> Tensor:
     """Score the global candidate batch ``edges`` [2, B] with the batch cut over the ranks of
     ``group``; every rank returns the full [B, 1] score vector, equal to the single-device result
@@ -214,6 +259,26 @@ def shard_plan(shape: str = "collab", worlds=(1, 2, 4, 8)) -> List[dict]:
     return rows
 
 
+def partition_plan(shape: str = "citation2", worlds=(1, 2, 4, 8), touched_cols: Optional[int] = None) -> List[dict]:
+    """What each partition of the scoring loop moves per candidate batch and rank (bytes; a dry run like ``shard_plan``):
+    ``intra_dense`` — the batch cut over the ranks, dense [N, 2] int64 histogram all-reduce (``sharded_predict``,
+    ``pipelined_shard_loop``); ``intra_sparse`` — the same cut, but only the touched columns' (column, counts) pairs
+    all-gathered (24 B per pair; NOT built: the figure is what it would move); ``dealt`` — whole batches dealt round robin
+    (``deal_batches``): nothing per batch, one all-gather of the scores per split.  ``touched_cols``: distinct columns with a
+    union entry per rank slice (default: batch x mean degree, an upper bound)."""
+    c = SHAPES[shape]
+    n, B = c["n"], c["batch"]
+    touched = touched_cols if touched_cols is not None else min(n, B * c["mean_deg"])
+    rows = []
+    for w in worlds:
+        dense = 0.0 if w == 1 else 2.0 * (w - 1) / w * n * 16
+        sparse = 0.0 if w == 1 else (w - 1) * touched * 24
+        rows.append(dict(shape=shape, world=w, intra_dense_MB=dense / 1e6, intra_sparse_MB=sparse / 1e6, dealt_MB=0.0,
+                         dealt_final_allgather_KB_per_batch=0.0 if w == 1 else (w - 1) * B * 4 / 1e3,
+                         sparse_pays=bool(w > 1 and touched < n / 8)))
+    return rows
+
+
 def shard_plan_markdown(shapes=("collab", "citation2"), worlds=(1, 2, 4, 8)) -> str:
     out = ["| shape | ranks | global batch | resident / GPU | of which A² + bit rows | h | histogram all-reduce / rank | floor, mesh / ring | "
            "score all-gather / rank | floor |", "|---|---|---|---|---|---|---|---|---|---|"]
@@ -227,3 +292,9 @@ def shard_plan_markdown(shapes=("collab", "citation2"), worlds=(1, 2, 4, 8)) -> 
 
 if __name__ == "__main__":
     print(shard_plan_markdown())
+    print()
+    print("| shape | ranks | intra-batch, dense all-reduce / rank | intra-batch, sparse pairs / rank (not built) | whole batches dealt: per batch | + scores at the end, per batch |")
+    print("|---|---|---|---|---|---|")
+    for sh, tc in (("collab", 180_000), ("citation2", 100_000)):
+        for r in partition_plan(sh, touched_cols=tc):
+            print(f"| {sh} | {r['world']} | {r['intra_dense_MB']:.2f} MB | {r['intra_sparse_MB']:.2f} MB | {r['dealt_MB']:.0f} | {r['dealt_final_allgather_KB_per_batch']:.0f} KB |")

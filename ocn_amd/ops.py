@@ -28,7 +28,8 @@ skip_zero_min_batch = 4096       # below this the extra small launches cost more
 walk_two_sided = True            # walk route: sweep each candidate from its cheaper endpoint (needs nds of the adjacency)
 walk_share_min = 2               # walk route, B <= 4096: candidates sharing a source are swept together from this group size on (0 = never)
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
-heavy_first = True               # ... and the pooling (H = 256) visits its slot groups longest first (ocn_cn_flags' gcost -> ocn_gather_schedule)
+heavy_first = os.environ.get("OCN_HEAVY_FIRST", "1") != "0"   # ... and the pooling (H = 256) visits its slot groups longest first (ocn_cn_flags' gcost -> ocn_gather_schedule)
+sched_segment = int(os.environ.get("OCN_SCHED_SEG", 0))        # ... inside segments of this many groups of an XCD's eighth (0 = the whole eighth)
 overlap_depth = int(os.environ.get("OCN_OVERLAP_DEPTH", 3))   # scratch sets of a predictor = the most batches a scoring loop keeps in flight
 overlap_deep_max_batch = int(os.environ.get("OCN_OVERLAP_DEEP_MAX_BATCH", 1 << 30))   # ... which it does for batches up to this size: every size by
                                  # default.  Two intersection passes beside one pooling + heads pay where phase A is the longer one: the drivers'
@@ -467,7 +468,7 @@ def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights
         n_groups = B // 4             # the intersection pass left the groups' costs in sched[:n_groups]; their visiting order follows
         perm = sched[n_groups:]
         if not sched_ready:           # (a scoring loop's phase A has run gather_schedule already)
-            check(_lib.lib().ocn_gather_schedule(ptr(sched), n_groups, ptr(perm), stream_ptr()), "ocn_gather_schedule")
+            check(_lib.lib().ocn_gather_schedule(ptr(sched), n_groups, int(sched_segment), ptr(perm), stream_ptr()), "ocn_gather_schedule")
     check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags),
                                    ptr(wc), ptr(weights), ptr(h), H, int(max_row_len), ptr(out[0]), ptr(out[1]),
                                    ptr(out[2]), ptr(out_row), ptr(cnt1), ptr(cnt2), ptr(rec), ptr(perm), ptr(rowsum),
@@ -487,7 +488,7 @@ def gather_schedule(sched: Tensor, B: int) -> bool:
     if sched is None or B % 32 != 0 or B // 32 > 65535 or B == 0:
         return False
     n_groups = B // 4
-    check(_lib.lib().ocn_gather_schedule(ptr(sched), n_groups, ptr(sched[n_groups:]), stream_ptr()), "ocn_gather_schedule")
+    check(_lib.lib().ocn_gather_schedule(ptr(sched), n_groups, int(sched_segment), ptr(sched[n_groups:]), stream_ptr()), "ocn_gather_schedule")
     _mark("cn_sched")
     return True
 

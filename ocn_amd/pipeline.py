@@ -22,13 +22,31 @@ from . import ops
 from .utils import PermIterator
 
 
+def _dealt(perms, group):
+    """(indices of the batches this rank scores, world size): whole batches dealt round robin over ``group`` (dist.deal_batches),
+    or every batch when there is no group / one rank / fewer batches than ranks."""
+    import torch.distributed as dist
+    from .dist import deal_batches
+    if group is None or not (dist.is_available() and dist.is_initialized()):
+        return list(range(len(perms))), 1
+    world = dist.get_world_size(group if group is not True else None)
+    if world == 1 or len(perms) < world:
+        return list(range(len(perms))), 1
+    return deal_batches(len(perms), world, dist.get_rank(group if group is not True else None)), world
+
+
 @torch.no_grad()
 def score_edges(predictor, h: Tensor, adj, adj2, edges: Tensor, batch_size: int, args=None,
-                run_ahead: int = 6) -> Tensor:
+                run_ahead: int = 6, group=None) -> Tensor:
     """Scores for ``edges`` [n, 2] (the layout of ``split_edge[...]['edge']``), batched like
     ``PermIterator(.., training=False)``; returns a [n] fp32 tensor on the device.  The host stays at
     most ``run_ahead`` batches ahead of the GPU: an unbounded backlog makes the HIP runtime block the
-    host until the queue has drained completely."""
+    host until the queue has drained completely.
+
+    ``group`` (a process group, or True for the default one): the ``PermIterator`` batches are DEALT round robin to the
+    ranks — every batch stays whole on one GPU, so its batch-coupled normalisation is the single-device one and no
+    histogram travels; ONE all-gather of the scores closes the split (``dist.gather_dealt``).  Every rank returns all n
+    scores, bit-equal to the single-process call."""
     from .utils import adjoverlap
     if predictor.training:
         raise RuntimeError("score_edges is the eval path; call predictor.eval() first")
@@ -42,32 +60,39 @@ def score_edges(predictor, h: Tensor, adj, adj2, edges: Tensor, batch_size: int,
     # the ids of the whole split are bounds-checked once; the batches then run without a host sync each
     with ops.prevalidated(edges[:, 0], edges[:, 1], adj.size(0), adj.size(0)):
         perms = list(PermIterator(edges.device, edges.shape[0], batch_size, training=False))
+        mine, world = _dealt(perms, group)
 
         def begin(it):
-            e = edges[perms[it]].t().contiguous()
+            e = edges[perms[mine[it]]].t().contiguous()
             return predictor.begin(h, adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e), e, slot=it, args=args)
 
         def flow(it):
             if len(done) >= max(run_ahead, 1):
                 done.pop(0).synchronize()
 
-        for out in overlapped_steps(begin, lambda tok: predictor.finish(h, tok, args), len(perms), before_step=flow, batch=batch_size,
+        for out in overlapped_steps(begin, lambda tok: predictor.finish(h, tok, args), len(mine), before_step=flow, batch=batch_size,
                                     device=h.device):
             outs.append(out.reshape(-1))
             done.append(torch.cuda.current_stream(h.device).record_event())
-    scores = torch.cat(outs, dim=0)
+    if world > 1:
+        from .dist import gather_dealt
+        scores = gather_dealt(outs, [int(p.numel()) for p in perms], None if group is True else group)
+    else:
+        scores = torch.cat(outs, dim=0)
     predictor.check_errors()       # the batches' sticky status words, read once per split (flag capacity, scan state)
     return scores
 
 
 @torch.no_grad()
 def score_mrr_split(predictor, h: Tensor, adj, source: Tensor, target: Tensor, target_neg: Tensor,
-                    batch_size: int, args=None, evaluator=None):
+                    batch_size: int, args=None, evaluator=None, group=None):
     """``test_split`` of the citation2 driver (NeighborOverlapCitation2.py:227-254): positives
     (source, target) and, per positive, ``target_neg.shape[1]`` negatives sharing its source, each
     scored through ``get_cn1_cn2`` in ``PermIterator(.., training=False)`` batches — same batch
     composition as the reference, scores kept on the device.  Returns (pos_pred [n], neg_pred [n, n_neg])
-    or, with an ``evaluator``, the mean of its ``mrr_list``."""
+    or, with an ``evaluator``, the mean of its ``mrr_list``.  ``group``: whole batches dealt over the ranks, as in
+    ``score_edges`` — the partition that suits the drivers' 2 048-candidate batches (a dense histogram all-reduce per such
+    batch costs more link time than the batch costs compute)."""
     from .utils import get_cn1_cn2
     if predictor.training:
         raise RuntimeError("score_mrr_split is the eval path; call predictor.eval() first")
@@ -79,16 +104,21 @@ def score_mrr_split(predictor, h: Tensor, adj, source: Tensor, target: Tensor, t
         adj.warm(walk=True)            # (degree sums of the two-sided sweep: built on the caller's stream, before the side streams fork)
         with ops.prevalidated(src_all, dst_all, adj.size(0), adj.size(0)):
             perms = list(PermIterator(src_all.device, src_all.shape[0], batch_size, training=False))
+            mine, world = _dealt(perms, group)
 
             def begin(it):
-                e = torch.stack((src_all[perms[it]], dst_all[perms[it]]))
+                e = torch.stack((src_all[perms[mine[it]]], dst_all[perms[mine[it]]]))
                 cn1, cn2 = get_cn1_cn2(adj, e)
                 return predictor.begin(h, adj, cn1, cn2, e, slot=it, args=args)
 
-            for out in overlapped_steps(begin, lambda tok: predictor.finish(h, tok, args), len(perms), batch=batch_size,
+            for out in overlapped_steps(begin, lambda tok: predictor.finish(h, tok, args), len(mine), batch=batch_size,
                                         device=h.device):
                 outs.append(out.reshape(-1))
-        scores = torch.cat(outs, dim=0)
+        if world > 1:
+            from .dist import gather_dealt
+            scores = gather_dealt(outs, [int(p.numel()) for p in perms], None if group is True else group)
+        else:
+            scores = torch.cat(outs, dim=0)
         predictor.check_errors()
         return scores
 
