@@ -156,7 +156,7 @@ def build_workload(args, dev, rank, world):
     enc = getattr(M, cfg["enc"])(fin, H, H, cfg["layers"], 0.05, cfg["ln"], cfg["res"], max_x, cfg["conv"], cfg["jk"], 0.0,
                                  xdropout=0.7, taildropout=0.3).to(dev).eval()
     pred = make_predictor(cfg, dev)
-    if args.innerprod:
+    if getattr(args, "innerprod", 0.0):
         pred.innerprod.fill_(args.innerprod)           # a trained checkpoint's buffer (order-exact S2 path of cn5)
     with torch.no_grad():
         h = enc(x, adj)
@@ -179,8 +179,8 @@ def build_workload(args, dev, rank, world):
     r, c, _ = adj.coo()
     rc, cc = r.cpu(), c.cpu()
     # `batches` global batches of world x B edges each, seeded 1, 2, ...; rank r owns slice r of each
-    per_rank = 1 if args.scaling == "strong" else world          # strong scaling: the configuration's one batch, cut over the ranks
-    edges = [sample_edges(rc, cc, n, cfg["batch"] * per_rank, seed=1 + b).to(dev) for b in range(max(args.batches, 1))]
+    per_rank = 1 if getattr(args, "scaling", "weak") == "strong" else world          # strong scaling: the configuration's one batch, cut over the ranks
+    edges = [sample_edges(rc, cc, n, cfg["batch"] * per_rank, seed=1 + b).to(dev) for b in range(max(getattr(args, "batches", 1), 1))]
     return dict(cfg=cfg, n=n, adj=adj, adj2=adj2, h=h.contiguous(), pred=pred, edges=edges, enc_s=t_enc, a2_s=t_a2,
                 graph_s=t_graph, nnz=adj.nnz(), nnz2=adj2.nnz() if adj2 is not None else None,
                 max_deg=adj.max_rowcount(), args=SimpleNamespace(sum=cfg["sum"]))

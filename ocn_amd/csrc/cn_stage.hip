@@ -52,6 +52,10 @@ __device__ __forceinline__ bool sampled_has(const int32_t* samp, const int32_t* 
 #ifndef OCN_X_SCHED_SHIFT
 #define OCN_X_SCHED_SHIFT 5
 #endif
+#ifndef OCN_X_POOL_LPE
+#define OCN_X_POOL_LPE 64    /* lanes per candidate of the H = 256 pooling (64: one candidate per wave) */
+#endif
+#define POOL_FOLD (OCN_WAVE / OCN_X_POOL_LPE)      /* 4-slot cost groups of the intersection pass per pooling workgroup */
 #define SCHED_GROUP (OCN_BLOCK / OCN_X_G)    /* slots per scheduling group: a workgroup of the intersection pass == one of the H = 256 pooling */
 
 // G lanes cooperate on one candidate edge (64/G edges per wave).  Measured on the collab-shaped
@@ -775,7 +779,11 @@ __device__ __forceinline__ void pool_range(i64 p_begin, i64 p_end, i64 a0, i64 b
           wwa[u] = __shfl(wa[t], sl, OCN_WAVE);
           wwb[u] = __shfl(wb[t], sl, OCN_WAVE);
           if (bsel[u] >= 0) {
+#ifdef OCN_X_ROWMASK   /* timing experiment (results wrong): every row fetch folded onto a table of OCN_X_ROWMASK + 1 rows — what the kernel costs when its rows are cache-resident */
+            const float4* row = h4 + (i64)(kk[u] & OCN_X_ROWMASK) * rowq + gl;
+#else
             const float4* row = h4 + (i64)kk[u] * rowq + gl;
+#endif
 #pragma unroll
             for (int v = 0; v < NV; ++v) x[u][v] = row[v * LPE];
           }
@@ -831,6 +839,12 @@ __device__ __forceinline__ void pool_store(i64 e, i64 i, i64 j, int gl, const fl
 #define GATHER_SLICE_MIN_BATCH 16384     /* candidates from which the pooling of H >= 256 runs one feature slice per XCD */
 #endif
 
+#ifdef OCN_X_POOL_STAMPS   /* diagnostic build (tools/poolstamps.py): per processing slot {start, end, row length, xcc | hw id} of its pooling wave */
+__device__ unsigned long long g_pool_stamps[4 << 17];
+extern "C" int ocn_debug_pool_stamps(unsigned long long* out, long long n_slots) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pool_stamps), (size_t)n_slots * 4 * sizeof(unsigned long long));
+}
+#endif
 // LPE lanes cooperate on one edge (64/LPE edges per wave).
 // SLICED: the H features are cut into 8 slices of LPE*NV*4 and workgroup b pools slice b % 8 of its candidates.
 // Workgroups are dealt round-robin over the 8 XCDs, so XCD x only ever reads feature slice x of the embedding
@@ -873,6 +887,9 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
   }
   const i64 slot = (bid * OCN_WPB + (threadIdx.x >> 6)) * GPW + lane / LPE;
   if (slot >= B) return;                    // whole group leaves together
+#ifdef OCN_X_POOL_STAMPS
+  const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
   // One dependent load instead of three (order -> src / dst / off / counts -> rowptr) in front of the first gather:
   // the intersection pass left everything about this slot in a 32-byte record.
   i64 e, i, j, a0, da, base;
@@ -909,6 +926,18 @@ __global__ __launch_bounds__(OCN_BLOCK) void cn_gather_kernel(
   }
   pool_store<LPE, NV>(out_row ? out_row[e] : e, i, j, gl, h4, rowq, acc1, acc2, xcn1, xcn2, xij,
                       !out_row || has1, !out_row || has1 || has2);
+#ifdef OCN_X_POOL_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  if (gl == 0 && slot < (1 << 17)) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_pool_stamps[4 * slot + 0] = t_start;
+    g_pool_stamps[4 * slot + 1] = __builtin_amdgcn_s_memtime();
+    g_pool_stamps[4 * slot + 2] = (unsigned long long)da;
+    g_pool_stamps[4 * slot + 3] = ((unsigned long long)(xcc & 0xf) << 32) | hwid;
+  }
+#endif
 }
 
 // The sequential sum of ranks [0, nr) of a compacted round: acc += w[r] * x[r], one multiply and one add per entry and
@@ -1534,7 +1563,7 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
                           const int32_t* cnt2, const uint64_t* rec, const int32_t* perm, const float* rowsum, hipStream_t st) {
   const i64 epb = (i64)OCN_WPB * (OCN_WAVE / LPE);
   // the schedule's groups are the workgroups of the intersection pass: usable where the pooling's workgroups are the same
-  const bool sched = perm && rec && epb == SCHED_GROUP && ((B + epb - 1) / epb) % 8 == 0;
+  const bool sched = perm && rec && epb == SCHED_GROUP * POOL_FOLD && ((B + epb - 1) / epb) % 8 == 0;
   bool packed = true;
   if constexpr (LPE <= 16) {
     if (B * LPE < 262144) {                  // the packed form would not fill the SIMDs
@@ -1749,7 +1778,10 @@ __global__ __launch_bounds__(OCN_BLOCK) void gather_schedule_kernel(const int32_
   const i64 ipt = (per + OCN_BLOCK - 1) / OCN_BLOCK;                          // groups per thread, contiguous
   for (int b = 0; b < SCHED_BUCKETS; ++b) tc[b * OCN_BLOCK + t] = 0;
   auto bucket = [&](i64 q) -> int {
-    const int c = gcost[lo + q] >> OCN_X_SCHED_SHIFT;
+    int c = 0;
+#pragma unroll
+    for (int f = 0; f < POOL_FOLD; ++f) c = SCHED_COST(c, gcost[(lo + q) * POOL_FOLD + f]);
+    c >>= OCN_X_SCHED_SHIFT;
     return SCHED_BUCKETS - 1 - (c < SCHED_BUCKETS - 1 ? c : SCHED_BUCKETS - 1);
   };
   for (i64 k = 0; k < ipt; ++k) {
@@ -1781,6 +1813,8 @@ int ocn_gather_schedule(const int32_t* gcost, int64_t n_groups, int64_t segment,
   if (n_groups < 0 || (n_groups & 7) || (n_groups >> 3) > 65535 || segment < 0) return OCN_EINVAL;      // eighths; ranks are 16-bit
   if (n_groups == 0) return 0;
   if (!gcost || !perm) return OCN_EINVAL;
+  if (n_groups % (8 * POOL_FOLD)) return OCN_EINVAL;
+  n_groups /= POOL_FOLD;
   i64 per = n_groups >> 3;
   if (segment > 0 && segment < per && per % segment == 0) per = segment;      // (a segment that does not divide the eighth: whole eighths)
   hipLaunchKernelGGL(gather_schedule_kernel, dim3((unsigned)(n_groups / per)), dim3(OCN_BLOCK), 0, (hipStream_t)stream, gcost, per, perm);
@@ -1803,7 +1837,7 @@ int ocn_cn_gather(const int64_t* rowptrA, const int32_t* colA, const int64_t* sr
     case 32:  LAUNCH_GATHER(8, 1); break;
     case 64:  LAUNCH_GATHER(16, 1); break;
     case 128: LAUNCH_GATHER(32, 1); break;
-    case 256: LAUNCH_GATHER(64, 1); break;
+    case 256: LAUNCH_GATHER(OCN_X_POOL_LPE, (64 / OCN_X_POOL_LPE)); break;
     case 512: LAUNCH_GATHER(64, 2); break;
     default:   /* generic widths: every row by one wave, no long-row split */
       hipLaunchKernelGGL(cn_gather_generic, dim3((unsigned)((B + OCN_WPB - 1) / OCN_WPB)),
