@@ -1600,16 +1600,22 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
 #define LONG_ARGS (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst, (i64)B, (const i64*)off, flags, wc, \
                   (const float4*)weights, h, (int)H, xcn1, xcn2, xij, (const i64*)out_row, cnt2, rowsum
   if (max_row_len > LONG_ROW) {
-    if (B <= 4096) {
-      static bool raised_dev[64] = {};        // 2 x 64 KiB of slab: above the default dynamic-LDS limit (attribute is per device)
-      int devid = 0;
-      if (hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < 64 && !raised_dev[devid]) {
-        if (hipFuncSetAttribute((const void*)cn_gather_long_kernel<LPE, NV, LONG_SMALL_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * LONG_SLAB_BYTES(LONG_SMALL_THREADS)) == hipSuccess) raised_dev[devid] = true;
+    // (H = 512 — two float4 per lane — does not fit the 128 registers a 1024-thread workgroup leaves a lane: 104 spilled
+    // VGPRs in round 3; it takes the 256-thread form at every batch size)
+    bool small = false;
+    if constexpr (NV == 1) {
+      if (B <= 4096) {
+        static bool raised_dev[64] = {};        // 2 x 64 KiB of slab: above the default dynamic-LDS limit (attribute is per device)
+        int devid = 0;
+        if (hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < 64 && !raised_dev[devid]) {
+          if (hipFuncSetAttribute((const void*)cn_gather_long_kernel<LPE, NV, LONG_SMALL_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * LONG_SLAB_BYTES(LONG_SMALL_THREADS)) == hipSuccess) raised_dev[devid] = true;
+        }
+        hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV, LONG_SMALL_THREADS>), dim3((unsigned)B), dim3(LONG_SMALL_THREADS), 2 * LONG_SLAB_BYTES(LONG_SMALL_THREADS), st, LONG_ARGS);
+        small = true;
       }
-      hipLaunchKernelGGL((cn_gather_long_kernel<LPE, NV, LONG_SMALL_THREADS>), dim3((unsigned)B), dim3(LONG_SMALL_THREADS), 2 * LONG_SLAB_BYTES(LONG_SMALL_THREADS), st, LONG_ARGS);
     }
-    else {
+    if (!small) {
       bool by_wave = false;
       if constexpr (LPE <= 16) {             // narrow embeddings: a wave per hub row, 64 gathers in flight each
         hipLaunchKernelGGL((cn_gather_wave_kernel<LPE, NV, true>), dim3((unsigned)B), dim3(OCN_WAVE), 0, st, (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst,

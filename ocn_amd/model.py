@@ -564,7 +564,7 @@ class _CNPredictorBase(nn.Module):
         waits for the sum."""
         if self._sharded:
             from .dist import allreduce_hist_finish, allreduce_hist_start
-            handle = allreduce_hist_start(st.hist, self._shard_group, valued=st.walk)
+            handle = allreduce_hist_start(st.hist, self._shard_group, valued=st.walk, slice_edges=st.B)
             st.sharded, st.shard_group = True, self._shard_group
             if x is not None:
                 self._class_order(st, x)
@@ -593,7 +593,7 @@ class _CNPredictorBase(nn.Module):
             else:
                 # the whole interleaved buffer, no copy-out / copy-back of the packed word: the collective is hidden behind the
                 # next batch's intersection pass, its extra bytes are free, the two copies were not
-                handle = allreduce_hist_start(st.hist, self._shard_group, valued=True)
+                handle = allreduce_hist_start(st.hist, self._shard_group, valued=True, slice_edges=st.B)
         # Unsharded, the batch's histogram is complete when the intersection pass ends: the column weights — and, for a
         # trained cn5 / cn6 (innerprod != 0), the order-exact column sums in front of them, 0.2 ms of latency-bound chains at
         # the collab shape — belong to phase A, which the scoring loops run beside the previous batch's pooling and heads.
@@ -614,7 +614,7 @@ class _CNPredictorBase(nn.Module):
         ops._mark("begin")                     # (stage timers: this phase may run on another stream than phase A did)
         if isinstance(handle, str):            # "late": the collective starts here, the class ordering runs beside it, and the
             from .dist import allreduce_hist_start      # next batch's phase A (another stream) fills the rest of the wait
-            handle = allreduce_hist_start(st.hist, self._shard_group, valued=True)
+            handle = allreduce_hist_start(st.hist, self._shard_group, valued=True, slice_edges=st.B)
         if not getattr(st, "_cls_decided", False):
             self._class_order(st, x)
         if handle is not None:

@@ -230,7 +230,7 @@ def test_heads_kernel_isa_audit():
 
 
 def test_training_and_sort_kernels_do_not_spill(tmp_path):
-    """The round-3 kernels of the training loop (COO -> CSR build with its row sorts, weight gradient, deterministic pooling
+    """The intersection / pooling / scan / column-sum kernels and the round-3 kernels of the training loop (COO -> CSR build with its row sorts, weight gradient, deterministic pooling
     backward): compiled for gfx950, none keeps a register in scratch and the weight-gradient kernel holds its MFMAs."""
     import os
     import re
@@ -238,7 +238,7 @@ def test_training_and_sort_kernels_do_not_spill(tmp_path):
     root = os.path.join(os.path.dirname(__file__), "..")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     seen = {}
-    for name in ("coo_csr", "wgrad", "pool_bwd"):
+    for name in ("coo_csr", "wgrad", "pool_bwd", "cn_stage", "scan", "colsum"):       # (cn_stage: round 3 shipped a 104-register spill in the H = 512 hub-row kernel)
         out = tmp_path / (name + ".s")
         subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S",
                         "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "ocn_amd", "csrc"),
