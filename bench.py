@@ -79,8 +79,14 @@ class StageTimer:
     heads) on the caller's, and an interval that starts at one stream's event and ends at another's measures nothing
     (VERDICT r3 #4).  Every phase opens with a "begin" mark on its own stream, so a stage interval never spans two phases."""
 
-    def __init__(self, pool=0):
+    # the stages the line's roofline objects need; the small phase-A kernels (weights, class order, schedule) are timed with
+    # --all-stages only: every recorded event costs the timed region (16 marks per sampled step: -5 % on the driver's
+    # 20-step run, measured; these 9: -2 %)
+    LEAN = frozenset(("begin", "cn_prep", "cn_flags", "cn_gather", "mlp_glue", "linear", "allreduce_hist"))
+
+    def __init__(self, pool=0, lean=True):
         self.events = []
+        self.lean = lean
         self.active = True
         self.flops = {}
         self.sampled_steps = 0
@@ -92,7 +98,7 @@ class StageTimer:
         self._raw = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
     def mark(self, name, flops=0.0):
-        if not self.active:
+        if not self.active or (self.lean and name not in self.LEAN):
             return
         self.flops[name] = self.flops.get(name, 0.0) + flops
         ev = self.pool.pop() if self.pool else torch.cuda.Event(enable_timing=True)
@@ -352,6 +358,8 @@ def main():
     ap.add_argument("--prewarm", type=int, default=64, help="untimed runtime pre-warm steps before --warmup")
     ap.add_argument("--run-ahead", type=int, default=6, help="steps the host may enqueue ahead of the GPU")
     ap.add_argument("--timer-every", type=int, default=0, help="record stage events on every n-th timed step (0 = steps // 8: at least 8 sampled steps)")
+    ap.add_argument("--all-stages", action="store_true", help="stage events for every kernel group of the step (default: the intersection, "
+                    "pooling and heads launches only — each recorded event costs the timed region)")
     ap.add_argument("--repeats", type=int, default=3, help="times the timed loop runs in all; `value` is the first run, the others are reported beside it")
     ap.add_argument("--rehearse-collectives", action="store_true",
                     help="one rank, but with the N > 1 code path: RCCL process group, histogram all-reduce and score "
@@ -527,7 +535,7 @@ def main():
             dt = tmax.item()
         return dt, t_launch, out
 
-    timer = None if args.no_stage_timers else StageTimer(pool=48 * (args.steps // max(args.timer_every or max(1, args.steps // 8), 1) + 2))
+    timer = None if args.no_stage_timers else StageTimer(pool=48 * (args.steps // max(args.timer_every or max(1, args.steps // 8), 1) + 2), lean=not args.all_stages)
     dt, t_launch, out = timed_loop(args.steps, timer)
     pattern_main = pattern[0]
     # the same timed loop again (no stage events): the spread of the step time from run to run, reported beside `value`
@@ -540,7 +548,7 @@ def main():
     overlapped = pipelined and "HIP stream" in pattern_main
     if overlapped and not args.no_stage_timers and not args.no_one_stream_leg:
         n1 = min(args.steps, 64)
-        timer1 = StageTimer(pool=48 * (n1 // max(args.timer_every or max(1, n1 // 8), 1) + 2))
+        timer1 = StageTimer(pool=48 * (n1 // max(args.timer_every or max(1, n1 // 8), 1) + 2), lean=not args.all_stages)
         dt1, _, _ = timed_loop(n1, timer1, overlap=False)
         dt1 /= n1
         pattern[0] = pattern_main

@@ -55,7 +55,7 @@ def child():
         t.sort()
         return t[len(t) // 2], t[0]
 
-    tm = bench.StageTimer(pool=16 * (iters + 2))
+    tm = bench.StageTimer(pool=16 * (iters + 2), lean=False)
     ops.stage_timer = tm
     for _ in range(iters + 2):
         tm.mark("begin")

@@ -20,7 +20,9 @@ for C in $CFGS; do
   python3 tools/pmc_summary.py $O/${R}_pmc${S}.json $O/${R}_pmc_fetch $O/${R}_pmc_write $O/${R}_pmc_l2 $O/${R}_pmc_mfma
   cp $O/${R}_pmc${S}.json profiles/${R}_pmc${S}.json
   timeout -k 10 500 python3 bench.py --config $C > $O/${R}_bench_${C}.json 2> $O/${R}_bench_${C}.err
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/${R}_prof -o run --output-format csv -- python3 bench.py --config $C --no-cpu-baseline --no-validate-leg --steps 64 > $O/${R}_bench_prof_${C}.json 2> $O/${R}_prof.err
+  # the kernel trace is taken on the DRIVER's command shape (20 steps, 5 warm-up) without the serialised-streams leg, so that
+  # its per-kernel averages are over the overlapped loop the line's own stage events sample
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $O/${R}_prof -o run --output-format csv -- python3 bench.py --config $C --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-validate-leg --no-one-stream-leg > $O/${R}_bench_prof_${C}.json 2> $O/${R}_prof.err
   cp $(find $O/${R}_prof -name '*kernel_stats.csv' | head -1) $O/${R}_bench${S}_kernel_stats.csv
   rm -rf $O/${R}_prof $O/${R}_pmc_fetch $O/${R}_pmc_write $O/${R}_pmc_l2 $O/${R}_pmc_mfma      # raw traces: tens of MB, gpurun_out is capped
   echo "== $C"; head -c 400 $O/${R}_bench_${C}.json; echo
