@@ -778,6 +778,12 @@ __device__ __forceinline__ void pool_range(i64 p_begin, i64 p_end, i64 a0, i64 b
           kk[u] = __shfl(k[t], sl, OCN_WAVE);
           wwa[u] = __shfl(wa[t], sl, OCN_WAVE);
           wwb[u] = __shfl(wb[t], sl, OCN_WAVE);
+#ifdef OCN_X_ROWSKIP   /* timing experiment (results wrong): only every OCN_X_ROWSKIP-th entry fetches its row, the others reuse it — what perfect in-register row sharing would leave of the launch */
+          if (bsel[u] >= 0 && (u % OCN_X_ROWSKIP) != 0) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) x[u][v] = x[u - (u % OCN_X_ROWSKIP)][v];
+          } else
+#endif
           if (bsel[u] >= 0) {
 #ifdef OCN_X_ROWMASK   /* timing experiment (results wrong): every row fetch folded onto a table of OCN_X_ROWMASK + 1 rows — what the kernel costs when its rows are cache-resident */
             const float4* row = h4 + (i64)(kk[u] & OCN_X_ROWMASK) * rowq + gl;
