@@ -32,7 +32,8 @@ extern "C" {
  * 7: + ocn_coo_to_csr, ocn_wgrad, ocn_cn_gather_backward_det, ocn_gather_schedule; ocn_cn_flags gains `gcost`,
  *    ocn_cn_gather gains `perm` and `rowsum`.
  * 8: a scan whose workspace was not zero ends in OCN_SCAN_POISON totals and a status bit instead of a GPU trap; `status` is
- *    int32[4] for every intersection entry, word 3 the sticky error word. */
+ *    int32[4] for every intersection entry, word 3 the sticky error word; ocn_cn_weights_cn7 takes the Chebyshev diagonals,
+ *    ocn_gather_schedule a segment; + ocn_cn_gather3_backward, ocn_cn_gather_backward_det_lists, ocn_ln_drop_relu_*. */
 #define OCN_ABI_VERSION 8
 #define OCN_EINVAL (-1)   /* null pointer / negative size / unsupported combination */
 #define OCN_ECAP   (-2)   /* reported through the device status word: flags capacity too small */
@@ -518,6 +519,24 @@ int ocn_coo_to_csr(const int64_t* row, const int64_t* col, int64_t nnz, int64_t 
 int64_t ocn_wgrad_workspace_bytes(int64_t B, int32_t N, int32_t K);
 int ocn_wgrad(const float* dY, int64_t ldY, const float* X, int64_t ldX, int64_t B, int32_t N, int32_t K,
               float* dW, float* db, void* workspace, void* stream);
+
+/* The heads' LayerNorm -> Dropout -> ReLU tails under autograd (the nn.Sequential layouts of model.py:2203-2235 in train(),
+ * NeighborOverlap_large.py:76-90), one forward and two backward launches:
+ *   y = relu?( dropout_p( gamma == NULL ? x : LN(x; gamma, beta, eps) ) ),   x, y [rows][H] fp32, H in {16 .. 512}
+ * stats (with gamma): float[rows][2] = {mean, 1 / sqrt(var + eps)} for the backward.  Dropout keeps an element iff a
+ * counter-based hash of (seed, element index) passes p — no mask is stored; the backward recomputes it from the same seed
+ * (ocn_dropout_keep_mask exposes the decisions for tests).  This is the library's random stream, not torch's.
+ * backward: dx; with gamma also dgamma / dbeta — every one of a FIXED number of lane groups walks a contiguous block of rows
+ * and keeps its own partial sums, a second launch adds them in block order: the same bits on every run.
+ * workspace: ocn_ln_drop_relu_workspace_bytes(H) (with gamma). */
+int64_t ocn_ln_drop_relu_workspace_bytes(int32_t H);
+int ocn_ln_drop_relu_forward(const float* x, const float* gamma /* or NULL */, const float* beta /* or NULL */, float eps, float p,
+                             uint64_t seed, int32_t relu, int64_t rows, int32_t H, float* y, float* stats /* [rows][2], with gamma */,
+                             void* stream);
+int ocn_ln_drop_relu_backward(const float* g, const float* x, const float* y, const float* stats, const float* gamma /* or NULL */,
+                              float p, uint64_t seed, int32_t relu, int64_t rows, int32_t H, float* dx,
+                              float* dgamma, float* dbeta, void* workspace, void* stream);
+int ocn_dropout_keep_mask(uint64_t seed, float p, int64_t n, uint8_t* out, void* stream);
 
 #ifdef __cplusplus
 }

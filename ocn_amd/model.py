@@ -499,14 +499,56 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw, gb
 
 
+class _TailFn(torch.autograd.Function):
+    """y = ReLU?(Dropout_p(LayerNorm?(x))) — the tail between two Linear layers of the heads (model.py:2203-2235) — as one
+    launch each way (ocn_ln_drop_relu_forward / _backward).  The dropout decisions come from a counter-based hash of a seed
+    drawn from torch's CPU generator (``torch.manual_seed`` makes a run repeatable; no host sync) and are recomputed in the
+    backward; they are this library's random stream, not torch's Philox."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, p, relu):
+        seed = int(torch.randint(0, 1 << 62, (1,)).item()) if p > 0.0 else 0
+        y, stats = ops.ln_drop_relu_forward(x, gamma, beta, eps, p, seed, relu)
+        ctx.save_for_backward(x, y, stats, gamma)
+        ctx.cfg = (p, seed, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, stats, gamma = ctx.saved_tensors
+        p, seed, relu = ctx.cfg
+        dx, dg, db = ops.ln_drop_relu_backward(g, x, y, stats, gamma, p, seed, relu)
+        return dx, dg, db, None, None, None
+
+
 def _seq_train(seq: nn.Sequential, x: Tensor) -> Tensor:
     """Autograd-mode walk of one of the predictor's heads: every ``nn.Linear`` the MFMA kernel takes runs through
-    ``_LinearFn``; Dropout / LayerNorm / ReLU stay the torch modules (their backward is torch's)."""
-    for m in seq:
+    ``_LinearFn``; a ``[LayerNorm] [Dropout] [ReLU]`` run between them through ``_TailFn`` (one launch each way); anything
+    else stays the torch module."""
+    mods = [m for m in seq if not isinstance(m, nn.Identity)]
+    i = 0
+    while i < len(mods):
+        m = mods[i]
         if isinstance(m, nn.Linear) and x.dim() == 2 and x.is_contiguous() and ops.linear_ok(x, m.weight):
             x = _LinearFn.apply(x, m.weight, m.bias)
-        else:
-            x = m(x)
+            i += 1
+            continue
+        if (ops.train_tails and isinstance(m, (nn.LayerNorm, nn.Dropout, nn.ReLU)) and x.is_cuda and x.dim() == 2
+                and x.dtype == torch.float32 and x.shape[1] in ops.LN_WIDTHS):
+            j, ln, p, relu = i, None, 0.0, False
+            if isinstance(mods[j], nn.LayerNorm) and mods[j].elementwise_affine and tuple(mods[j].normalized_shape) == (x.shape[1],):
+                ln, j = mods[j], j + 1
+            if j < len(mods) and isinstance(mods[j], nn.Dropout):
+                p, j = (float(mods[j].p) if mods[j].training else 0.0), j + 1
+            if j < len(mods) and isinstance(mods[j], nn.ReLU):
+                relu, j = True, j + 1
+            if j > i and p < 1.0:
+                x = _TailFn.apply(x.contiguous(), None if ln is None else ln.weight, None if ln is None else ln.bias,
+                                  0.0 if ln is None else ln.eps, p, relu)
+                i = j
+                continue
+        x = m(x)
+        i += 1
     return x
 
 

@@ -236,7 +236,9 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     if not walk:
         _req(t1[0], torch.int64, "rowptrT1", 1); _req(t1[1], torch.int32, "colT1", 1)
         if t2 is not None:
-            _req(t2[0], torch.int64, "rowptrT2", 1); _req(t2[1], torch.int32, "colT2", 1)
+            _req(t2[0], torch.int64, "rowptrT2", 1)
+            if t2[1] is not None or t2_bitmap is None:           # (with bit rows the kernel never reads T2's column ids: they may be deferred)
+                _req(t2[1], torch.int32, "colT2", 1)
     _req(src, torch.int64, "src", 1); _req(dst, torch.int64, "dst", 1)
     if dst.numel() != B:
         raise ValueError("src/dst length mismatch")
@@ -656,9 +658,11 @@ def bitrows_from_csr(rowptr: Tensor, col: Tensor, n_cols: int) -> Tensor:
 
 
 @_on_device
-def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int):
+def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int, defer_fill: bool = False):
     """CSR pattern of A·B (columns ascending) and, when it fits ``a2_bitmap_max_bytes``, the same
-    rows as dense bit rows.  One host sync for the output size."""
+    rows as dense bit rows.  One host sync for the output size — with ``defer_fill`` and bit rows, not before somebody calls
+    the returned thunk: ``(rowptrC, fill, bitmap)`` where ``fill()`` -> colC runs the second pass (the counting pass, the scan
+    of the row lengths and the bit rows are done)."""
     _req(rowptrA, torch.int64, "rowptrA", 1); _req(colA, torch.int32, "colA", 1)
     _req(rowptrB, torch.int64, "rowptrB", 1); _req(colB, torch.int32, "colB", 1)
     l = _lib.lib()
@@ -676,12 +680,18 @@ def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int):
     check(l.ocn_spgemm_pattern_count(ptr(rowptrA), ptr(colA), n, ptr(rowptrB), ptr(colB), n_cols_b,
                                      ptr(cnt), ptr(bitmap), words, stream_ptr()), "ocn_spgemm_pattern_count")
     rowptrC = scan_i32(cnt)
-    nnz = _total(rowptrC[-1])
-    colC = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
-    if nnz:
-        check(l.ocn_spgemm_pattern_fill(ptr(rowptrA), ptr(colA), n, ptr(rowptrB), ptr(colB), n_cols_b,
-                                        ptr(rowptrC), ptr(colC), stream_ptr()), "ocn_spgemm_pattern_fill")
-    return rowptrC, colC, bitmap
+
+    def fill() -> Tensor:
+        nnz = _total(rowptrC[-1])
+        colC = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
+        if nnz:
+            with torch.cuda.device(dev):
+                check(l.ocn_spgemm_pattern_fill(ptr(rowptrA), ptr(colA), n, ptr(rowptrB), ptr(colB), n_cols_b,
+                                                ptr(rowptrC), ptr(colC), stream_ptr()), "ocn_spgemm_pattern_fill")
+        return colC
+    if defer_fill and bitmap is not None:
+        return rowptrC, fill, bitmap
+    return rowptrC, fill(), bitmap
 
 
 dense_adj2_max_nodes = 32768      # block route: A as a dense int8 matrix (n^2 bytes, twice) up to this many nodes
@@ -731,6 +741,46 @@ def rows_ln_relu(x: Tensor, gamma: Tensor, beta: Tensor, eps: float, relu: bool,
     check(_lib.lib().ocn_rows_ln_relu(ptr(x), ptr(gamma), ptr(beta), float(eps), int(relu), rows, H, ptr(y),
                                       stream_ptr()), "ocn_rows_ln_relu")
     return y
+
+
+@_on_device
+def ln_drop_relu_forward(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float, p: float, seed: int, relu: bool):
+    """y = relu?(dropout_p(LN?(x))) in one launch (ocn_hip.h: ocn_ln_drop_relu_forward); returns (y, stats | None)."""
+    _req(x, torch.float32, "x", 2)
+    rows, H = x.shape
+    if H not in LN_WIDTHS:
+        raise ValueError("ln_drop_relu: unsupported width")
+    if gamma is not None and (_req(gamma, torch.float32, "gamma", 1).numel() != H or _req(beta, torch.float32, "beta", 1).numel() != H):
+        raise ValueError("ln_drop_relu: gamma / beta width")
+    y = torch.empty_like(x)
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device) if gamma is not None else None
+    check(_lib.lib().ocn_ln_drop_relu_forward(ptr(x), ptr(gamma), ptr(beta), float(eps), float(p), int(seed), int(relu), rows, H, ptr(y),
+                                              ptr(stats), stream_ptr()), "ocn_ln_drop_relu_forward")
+    return y, stats
+
+
+@_on_device
+def ln_drop_relu_backward(g: Tensor, x: Tensor, y: Tensor, stats: Optional[Tensor], gamma: Optional[Tensor], p: float, seed: int,
+                          relu: bool):
+    """(dx, dgamma | None, dbeta | None) of ``ln_drop_relu_forward`` (deterministic: ocn_hip.h)."""
+    g = _req(g.contiguous(), torch.float32, "g", 2)
+    rows, H = g.shape
+    dx = torch.empty_like(g)
+    dg = db = ws = None
+    if gamma is not None:
+        dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty(int(_lib.lib().ocn_ln_drop_relu_workspace_bytes(H)), dtype=torch.uint8, device=g.device)
+    check(_lib.lib().ocn_ln_drop_relu_backward(ptr(g), ptr(x), ptr(y), ptr(stats), ptr(gamma), float(p), int(seed), int(relu), rows, H,
+                                               ptr(dx), ptr(dg), ptr(db), ptr(ws), stream_ptr()), "ocn_ln_drop_relu_backward")
+    return dx, dg, db
+
+
+@_on_device
+def dropout_keep_mask(seed: int, p: float, n: int, device) -> Tensor:
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    with torch.cuda.device(out.device):
+        check(_lib.lib().ocn_dropout_keep_mask(int(seed), float(p), n, ptr(out), stream_ptr()), "ocn_dropout_keep_mask")
+    return out
 
 
 @_on_device
@@ -808,6 +858,7 @@ def heads_panel(weight: Tensor):
 
 HEADS_WIDTHS = (128, 256)
 train_linear = True              # autograd on: the heads' Linear layers (forward and input gradient) on the MFMA kernel
+train_tails = os.environ.get("OCN_TRAIN_TAILS", "1") != "0"      # ... and their LayerNorm -> Dropout -> ReLU tails as one launch each way (ocn_ln_drop_relu_*)
 fused_heads = True               # cn5 / cn7 eval: the whole MLP head as one launch (ocn_heads_fused)
 fused_heads_min_width = 128      # narrower heads (ppa / citation2 / ddi: H = 32..64) have a k-loop of 2-4 steps: the fused
                                  # kernel's per-tile epilogues dominate and the grouped launches are faster (ddi: 18 vs 31 us)

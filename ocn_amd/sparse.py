@@ -88,6 +88,7 @@ class SparseTensor:
             torch.cumsum(cnt, 0, out=rowptr[1:])
             col = col64
         self._rowptr = rowptr.to(torch.int64).contiguous()
+        self._col_thunk = None
         self._col = col.to(torch.int32).contiguous()
         self._value = None if value is None else value.contiguous()
         self._row_cache: Optional[Tensor] = None
@@ -95,7 +96,42 @@ class SparseTensor:
         self._bitmap: Optional[Tensor] = None
         self._nds: Optional[Tensor] = None
         self._ready: dict = {}                 # cache name -> event recorded behind its asynchronous build
-        self.storage = _Storage(self)
+
+    @property
+    def storage(self) -> _Storage:
+        """``adj.storage.row() / .col() / .rowcount()`` (utils.py:42-44, 150-158).  A fresh view per access: an object that
+        held its storage while the storage held it back would be a reference cycle, freed only when Python's cycle collector
+        gets round to it — and a training loop's per-batch A² (7 GB of bit rows at the collab shape) must go when its step ends."""
+        return _Storage(self)
+
+    # The column ids of a PRODUCT (A @ A) may be deferred: its row pointers and dense bit rows come out of the counting pass, and
+    # on a large graph the intersection kernel probes the bit rows only (ocn_hip.h: ocn_cn_flags `bitmapT2`) — the fill pass
+    # (2.75 ms and a host sync for the output size per call at the collab shape: an eighth of a training step, which rebuilds
+    # A² of the masked graph per batch, NeighborOverlap_large.py:68-74) runs when somebody actually asks for the ids.
+    @property
+    def _col(self) -> Tensor:
+        if self._col_v is None and self._col_thunk is not None:
+            self._col_v, self._col_thunk = self._col_thunk(), None
+        return self._col_v
+
+    @_col.setter
+    def _col(self, v) -> None:
+        self._col_v = v
+
+    def col_materialized(self) -> bool:
+        return self._col_v is not None
+
+    @classmethod
+    def _deferred_product(cls, rowptr: Tensor, col_thunk, bitmap: Tensor, sparse_sizes) -> "SparseTensor":
+        out = cls.__new__(cls)
+        out._sizes = (int(sparse_sizes[0]), int(sparse_sizes[1]))
+        out._rowptr = rowptr
+        out._col_v, out._col_thunk = None, col_thunk
+        out._value = None
+        out._row_cache = out._maxdeg = out._nds = None
+        out._bitmap = bitmap
+        out._ready = {}
+        return out
 
     # ---- constructors ------------------------------------------------------------------
     @classmethod
@@ -146,7 +182,7 @@ class SparseTensor:
         return int(self._col.numel())
 
     def device(self):
-        return self._col.device
+        return self._rowptr.device
 
     def has_value(self) -> bool:
         return self._value is not None
@@ -174,9 +210,9 @@ class SparseTensor:
     # before the stream that is still filling it is done, so each cache carries the event recorded behind its build and
     # every later reader's stream waits for it — until the event has completed, after which it is dropped.
     def _published(self, name: str) -> None:
-        if self._col.is_cuda:
+        if self._rowptr.is_cuda:
             ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self._col.device))
+            ev.record(torch.cuda.current_stream(self._rowptr.device))
             self._ready[name] = ev
 
     def _await(self, name: str) -> None:
@@ -188,7 +224,7 @@ class SparseTensor:
         if ev.query():
             del self._ready[name]
         else:
-            torch.cuda.current_stream(self._col.device).wait_event(ev)
+            torch.cuda.current_stream(self._rowptr.device).wait_event(ev)
 
     def bit_rows(self) -> Optional[Tensor]:
         """The pattern as dense bit rows (cached, built once by ocn_bitrows_from_csr) when they fit
@@ -381,9 +417,12 @@ class CooView:
         a, b = self.sp, other.sp
         if a._sizes[1] != b._sizes[0]:
             raise ValueError("shape mismatch in sparse @ sparse")
-        rowptr, col, bitmap = ops.spgemm_pattern(a._rowptr, a._col, b._rowptr, b._col, b._sizes[1])
-        out = SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(a._sizes[0], b._sizes[1]))
-        out._bitmap = bitmap                   # dense bit rows of the product, probed by the intersection kernel
+        rowptr, col, bitmap = ops.spgemm_pattern(a._rowptr, a._col, b._rowptr, b._col, b._sizes[1], defer_fill=True)
+        if callable(col):                      # (bit rows exist: the column ids wait until somebody reads them)
+            out = SparseTensor._deferred_product(rowptr, col, bitmap, (a._sizes[0], b._sizes[1]))
+        else:
+            out = SparseTensor(rowptr=rowptr, col=col, sparse_sizes=(a._sizes[0], b._sizes[1]))
+            out._bitmap = bitmap               # dense bit rows of the product, probed by the intersection kernel
         if bitmap is not None:
             out._published("bitmap")
         return CooView(out, is_product=True)

@@ -71,7 +71,8 @@ class CNState:
                       if (self.rec is not None and ops.heavy_first and self.B >= ops.sort_edges_min_batch) else None)
         (self.order, self.off, self.flags, self.wc, self.hist, self.cnt1, self.cnt2, self.status, self.scal) = ops.cn_flags(
             adj._rowptr, adj._col, None if walk else (t1._rowptr, t1._col),
-            None if (walk or t2 is None) else (t2._rowptr, t2._col), self.src, self.dst, self.N,
+            None if (walk or t2 is None) else (t2._rowptr, t2._col if (t2.col_materialized() or t2._bitmap is None) else None),
+            self.src, self.dst, self.N,
             adj.max_rowcount(), walk=walk, t2_bitmap=None if (walk or t2 is None) else t2.product_bit_rows(), wsd=ws,
             nds=adj.neighbor_degree_sum() if (walk and ops.walk_two_sided) else None,
             t1_bitmap=None if walk else t1.bit_rows(), rec=self.rec, sched=self.sched)

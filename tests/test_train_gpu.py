@@ -202,3 +202,106 @@ def test_pooling_backward_is_deterministic_and_equals_the_atomic_form(hiplib, mo
     monkeypatch.setattr(ops, "deterministic_backward", False)
     c = grad()
     assert (a - c).abs().max().item() <= 2e-5 * max(1.0, c.abs().max().item())
+
+
+def test_product_column_ids_are_deferred_until_read(hiplib):
+    """A @ A on a graph whose product comes with dense bit rows: the counting pass, the scan of the row lengths and the bit rows
+    are done at once, the FILL pass (and its host sync for the output size) only when the column ids are read — the
+    intersection pass probes the bit rows and never reads them, so a training step that rebuilds A² per batch
+    (NeighborOverlap_large.py:68-74) skips it.  Same flags, counts and histograms as with the ids present; the ids, once
+    read, are the eager product's."""
+    from oracle import ocn_oracle as O
+    from ocn_amd.utils import CNState
+    from tests.helpers import batch, make_graph, to_product
+    oadj = make_graph(3000, 12, 400, seed=2)
+    adj = to_product(oadj, DEV)
+    sp = adj.to_torch_sparse_coo_tensor()
+    lazy = SparseTensor.from_torch_sparse_coo_tensor(sp @ sp, False)
+    assert lazy._bitmap is not None and not lazy.col_materialized()
+    e = batch(oadj, 2048, 7).to(DEV)
+    st = CNState(adj, adj, lazy, e)
+    assert not lazy.col_materialized()                          # the intersection pass did not need them
+    rowptr, col, _ = ops.spgemm_pattern(adj._rowptr, adj._col, adj._rowptr, adj._col, adj.size(1))      # the eager form
+    eager = SparseTensor(rowptr=rowptr, col=col, sparse_sizes=adj.sparse_sizes())
+    eager._bitmap = None                                        # ... searched as a CSR row, not probed
+    ref = CNState(adj, adj, eager, e)
+    assert torch.equal(st.flags[: int(st.off[-1])], ref.flags[: int(ref.off[-1])])
+    assert torch.equal(st.cnt1, ref.cnt1) and torch.equal(st.cnt2, ref.cnt2) and torch.equal(st.hist, ref.hist)
+    assert torch.equal(lazy._rowptr, rowptr)
+    assert lazy.nnz() == col.numel() and lazy.col_materialized() and torch.equal(lazy._col, col)
+    oadj2 = O.adj2_sparse(oadj)
+    r, c, _ = lazy.coo()
+    assert r.cpu().tolist() == oadj2.row.tolist() and c.cpu().tolist() == oadj2.col.tolist()
+
+
+@pytest.mark.parametrize("H,rows", [(32, 1000), (64, 4097), (256, 20000), (512, 333), (16, 70000)])
+@pytest.mark.parametrize("ln,relu,p", [(True, True, 0.0), (True, True, 0.3), (False, True, 0.05), (True, False, 0.0), (False, False, 0.5)])
+def test_ln_dropout_relu_tail_matches_torch_autograd(hiplib, H, rows, ln, relu, p):
+    """ocn_ln_drop_relu_forward / _backward (the heads' tails under autograd): values and all three gradients against torch
+    autograd of relu(LN(x) * keep / (1 - p)) with the SAME keep decisions (ocn_dropout_keep_mask), two runs bit-equal, and the
+    keep rate is p's."""
+    torch.manual_seed(H + rows)
+    x = torch.randn(rows, H, device=DEV) * 2.0 + 0.3
+    gamma = (torch.rand(H, device=DEV) + 0.5) if ln else None
+    beta = torch.randn(H, device=DEV) if ln else None
+    seed = 123456789 + H
+    y, stats = ops.ln_drop_relu_forward(x, gamma, beta, 1e-5, p, seed, relu)
+    keep = ops.dropout_keep_mask(seed, p, rows * H, DEV).view(rows, H).float() if p > 0 else torch.ones_like(x)
+    if p > 0:
+        assert abs(keep.mean().item() - (1 - p)) < 0.01
+    xr = x.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True) if ln else None
+    br = beta.clone().requires_grad_(True) if ln else None
+    u = torch.nn.functional.layer_norm(xr, (H,), gr, br, 1e-5) if ln else xr
+    d = u * keep / (1 - p)
+    ref = torch.relu(d) if relu else d
+    assert (y - ref).abs().max().item() <= 1e-5 * max(1.0, ref.abs().max().item())
+    g = torch.randn(rows, H, device=DEV)
+    ref.backward(g)
+    dx, dg, db = ops.ln_drop_relu_backward(g, x, y, stats, gamma, p, seed, relu)
+    assert (dx - xr.grad).abs().max().item() <= 2e-5 * max(1.0, xr.grad.abs().max().item())
+    if ln:
+        assert (dg - gr.grad).abs().max().item() <= 2e-5 * max(1.0, gr.grad.abs().max().item()) * (rows ** 0.5)
+        assert (db - br.grad).abs().max().item() <= 2e-5 * max(1.0, br.grad.abs().max().item()) * (rows ** 0.5)
+    dx2, dg2, db2 = ops.ln_drop_relu_backward(g, x, y, stats, gamma, p, seed, relu)
+    assert torch.equal(dx, dx2) and (not ln or (torch.equal(dg, dg2) and torch.equal(db, db2)))
+
+
+def test_heads_tails_run_fused_under_autograd(hiplib, monkeypatch):
+    """`_seq_train` routes the [LayerNorm] [Dropout] [ReLU] runs of the heads through the fused tail: with p = 0 the training-
+    mode scores and every gradient equal the torch-module walk to rounding; with the drivers' dropout the step runs, is
+    repeatable under torch.manual_seed, and the number of torch LayerNorm calls is zero."""
+    from types import SimpleNamespace
+    import torch.nn as nn
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.utils import adjoverlap
+    from tests.helpers import batch, make_graph, product_adj2, to_product
+    n, H, B = 3000, 64, 2048
+    oadj = make_graph(n, 12, 400, seed=2)
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    e = batch(oadj, B, 4).to(DEV)
+    torch.manual_seed(5)
+    x = torch.randn(n, H, device=DEV)
+
+    def run(pred, fused, seed=0):
+        monkeypatch.setattr(ops, "train_tails", fused)
+        torch.manual_seed(seed)
+        pred.zero_grad()
+        xd = x.clone().requires_grad_(True)
+        out = pred(xd, adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e), e, SimpleNamespace(sum=1.0))
+        out.sum().backward()
+        return out.detach().clone(), xd.grad.clone(), {k: p.grad.clone() for k, p in pred.named_parameters() if p.grad is not None}
+
+    pred0 = predictor_dict["cn5"](H, H, 1, 3, 0.0, 0.0, True).to(DEV).train()        # dropout p = 0: both walks are deterministic
+    a, b = run(pred0, True), run(pred0, False)
+    assert (a[0] - b[0]).abs().max().item() <= 1e-5 and (a[1] - b[1]).abs().max().item() <= 2e-5 * max(1.0, b[1].abs().max().item())
+    for k in b[2]:
+        assert (a[2][k] - b[2][k]).abs().max().item() <= 2e-5 * max(1.0, b[2][k].abs().max().item()) * 8, k
+    pred = predictor_dict["cn5"](H, H, 1, 3, 0.3, 0.0, True).to(DEV).train()
+    calls = []
+    hook = nn.LayerNorm.forward
+    monkeypatch.setattr(nn.LayerNorm, "forward", lambda self, t: (calls.append(1), hook(self, t))[1])
+    c, d = run(pred, True, seed=11), run(pred, True, seed=11)
+    assert not calls and torch.equal(c[0], d[0]) and torch.equal(c[1], d[1])
+    assert not torch.equal(c[0], run(pred, True, seed=12)[0])                          # another seed, another mask

@@ -49,7 +49,7 @@ def main():
     negedge = torch.randint(0, n, pos_train_edge.shape, device=dev)
     model.train(); predictor.train()
     adjmask = torch.ones_like(pos_train_edge[0], dtype=torch.bool)
-    times, losses = [], []
+    times, losses, mallocs = [], [], []
     it = iter(PermIterator(dev, adjmask.shape[0], B))
     for step in range(a.warmup + a.steps):
         try:
@@ -81,9 +81,13 @@ def main():
         if step >= a.warmup:
             times.append(time.perf_counter() - t0)
             losses.append(float(loss))
+            ms = torch.cuda.memory_stats()
+            mallocs.append((ms.get("num_device_alloc", 0), ms.get("num_device_free", 0), ms.get("num_alloc_retries", 0),
+                            round(ms.get("reserved_bytes.all.current", 0) / 2**30, 2)))
     print(json.dumps({"workload": f"{a.config}-shaped synthetic graph, training step of the reference driver (maskinput, A^2 per batch, "
                                   f"pos + neg pass, backward, Adam), batch {B}", "n": n, "train_edges": int(pos_train_edge.shape[1]),
                       "steps": a.steps, "ms_per_step": 1e3 * sum(times) / len(times), "ms_min": 1e3 * min(times),
+                      "ms_median": 1e3 * sorted(times)[len(times) // 2], "ms_steps": [round(1e3 * t, 2) for t in times], "allocator": mallocs,
                       "edges_per_s": 2 * B * len(times) / sum(times), "loss_first": losses[0], "loss_last": losses[-1],
                       "deterministic_backward": bool(ops.deterministic_backward)}))
 
