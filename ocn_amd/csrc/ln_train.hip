@@ -156,28 +156,34 @@ __global__ __launch_bounds__(OCN_BLOCK) void ln_drop_relu_bwd_kernel(
 }
 
 // dgamma[c] = sum over blocks of part[b][0][c], dbeta likewise, in a FIXED order: a workgroup owns 64 columns of one of the two
-// vectors; its wave w adds the blocks b = w, w + 4, w + 8, ... (64 coalesced floats per block, eight loads in flight), the four
-// wave sums are added ((s0 + s1) + s2) + s3.
-__global__ __launch_bounds__(OCN_BLOCK) void ln_partials_reduce_kernel(const float* __restrict__ part, i64 n_blocks, int H,
-                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ float sh[OCN_WPB][OCN_WAVE];
+// vectors; its wave w of 16 adds the blocks b = w, w + 16, w + 32, ... (64 coalesced floats per block, eight loads in flight),
+// the sixteen wave sums are added in wave order.
+#define LN_RED_WAVES 16
+__global__ __launch_bounds__(LN_RED_WAVES * OCN_WAVE) void ln_partials_reduce_kernel(const float* __restrict__ part, i64 n_blocks, int H,
+                                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float sh[LN_RED_WAVES][OCN_WAVE];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int G = (H + OCN_WAVE - 1) / OCN_WAVE;   // column groups of 64 per vector; the grid is 2 G: [dgamma groups | dbeta groups]
   const int which = blockIdx.x / G, col = (blockIdx.x % G) * OCN_WAVE + lane;
   const bool ok = col < H;
   float s = 0.f;
   i64 b = w;
-  for (; b + 7 * OCN_WPB < n_blocks; b += 8 * OCN_WPB) {
+  for (; b + 7 * LN_RED_WAVES < n_blocks; b += 8 * LN_RED_WAVES) {
     float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = ok ? part[(2 * (b + u * OCN_WPB) + which) * H + col] : 0.f;
+    for (int u = 0; u < 8; ++u) v[u] = ok ? part[(2 * (b + u * LN_RED_WAVES) + which) * H + col] : 0.f;
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += v[u];
   }
-  for (; b < n_blocks; b += OCN_WPB) s += ok ? part[(2 * b + which) * H + col] : 0.f;
+  for (; b < n_blocks; b += LN_RED_WAVES) s += ok ? part[(2 * b + which) * H + col] : 0.f;
   sh[w][lane] = s;
   __syncthreads();
-  if (w == 0 && ok) (which ? dbeta : dgamma)[col] = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+  if (w == 0 && ok) {
+    float t = sh[0][lane];
+#pragma unroll
+    for (int q = 1; q < LN_RED_WAVES; ++q) t += sh[q][lane];
+    (which ? dbeta : dgamma)[col] = t;
+  }
 }
 
 __global__ __launch_bounds__(OCN_BLOCK) void drop_mask_kernel(u64 seed, unsigned thresh, i64 n, uint8_t* __restrict__ out) {
@@ -248,7 +254,7 @@ int ocn_ln_drop_relu_backward(const float* g, const float* x, const float* y, co
   if (gamma) {
     // column groups of 64 over [dgamma | dbeta]; widths below 64 take one group per vector (lanes beyond H idle)
     const int groups_per_vec = (H + OCN_WAVE - 1) / OCN_WAVE;
-    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((unsigned)(2 * groups_per_vec)), dim3(OCN_BLOCK), 0,
+    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((unsigned)(2 * groups_per_vec)), dim3(LN_RED_WAVES * OCN_WAVE), 0,
                        (hipStream_t)stream, (const float*)part, (i64)LN_BWD_GROUPS, (int)H, dgamma, dbeta);
   }
   return launch_status();
