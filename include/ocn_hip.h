@@ -538,6 +538,13 @@ int ocn_ln_drop_relu_backward(const float* g, const float* x, const float* y, co
                               float* dgamma, float* dbeta, void* workspace, void* stream);
 int ocn_dropout_keep_mask(uint64_t seed, float p, int64_t n, uint8_t* out, void* stream);
 
+/* Backward of the branch mix z = coef[0] x1 + coef[1] x2 + coef[2] x3 (ocn_combine3; model.py:2436, 3222): d_k = coef[k] g and
+ * dcoef[k] = <g, x_k> — per-workgroup partial sums over contiguous chunks, added in workgroup order (deterministic).  n a
+ * multiple of 4; workspace: ocn_mix3_workspace_bytes(). */
+int64_t ocn_mix3_workspace_bytes(void);
+int ocn_mix3_backward(const float* coef, const float* g, const float* x1, const float* x2, const float* x3, int64_t n,
+                      float* d1, float* d2, float* d3, float* dcoef, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

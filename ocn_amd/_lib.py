@@ -68,6 +68,8 @@ SIGNATURES = {
     "ocn_ln_drop_relu_forward": (c_int32, [_P, _P, _P, c_float, c_float, ctypes.c_uint64, c_int32, c_int64, c_int32, _P, _P, _P]),
     "ocn_ln_drop_relu_backward": (c_int32, [_P, _P, _P, _P, _P, c_float, ctypes.c_uint64, c_int32, c_int64, c_int32, _P, _P, _P, _P, _P]),
     "ocn_dropout_keep_mask": (c_int32, [ctypes.c_uint64, c_float, c_int64, _P, _P]),
+    "ocn_mix3_workspace_bytes": (c_int64, []),
+    "ocn_mix3_backward": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "ocn_spmm_csr": (c_int32, [_P, _P, _P, c_int64, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, _P, _P]),
     "ocn_deg_rsqrt": (c_int32, [_P, _P, c_int64, c_float, _P, _P]),
     "ocn_spgemm_max_cols": (c_int64, []),

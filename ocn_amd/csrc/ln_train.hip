@@ -186,6 +186,45 @@ __global__ __launch_bounds__(LN_RED_WAVES * OCN_WAVE) void ln_partials_reduce_ke
   }
 }
 
+// The branch mix z = c0 x1 + c1 x2 + c2 x3 (model.py:2436 / 3222) under autograd: dx_k = c_k g in one pass, and the three dot
+// products <g, x_k> (the gradients of the coefficients, which torch's autograd carries on through sigmoid / cumprod) as
+// per-workgroup partial sums over contiguous chunks, added in workgroup order by one wave.
+#define MIX_GROUPS 1024
+__global__ __launch_bounds__(OCN_BLOCK) void mix3_bwd_kernel(const float* __restrict__ coef, const float4* __restrict__ g,
+                                                             const float4* __restrict__ x1, const float4* __restrict__ x2,
+                                                             const float4* __restrict__ x3, i64 n4, float4* __restrict__ d1,
+                                                             float4* __restrict__ d2, float4* __restrict__ d3, float* __restrict__ part) {
+  __shared__ float sh[3][OCN_WPB];
+  const float c0 = coef[0], c1 = coef[1], c2 = coef[2];
+  const i64 chunk = (n4 + MIX_GROUPS - 1) / MIX_GROUPS;
+  const i64 lo = (i64)blockIdx.x * chunk, hi = lo + chunk < n4 ? lo + chunk : n4;
+  float s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (i64 q = lo + threadIdx.x; q < hi; q += OCN_BLOCK) {
+    const float4 gv = g[q], a = x1[q], b = x2[q], c = x3[q];
+    d1[q] = make_float4(c0 * gv.x, c0 * gv.y, c0 * gv.z, c0 * gv.w);
+    d2[q] = make_float4(c1 * gv.x, c1 * gv.y, c1 * gv.z, c1 * gv.w);
+    d3[q] = make_float4(c2 * gv.x, c2 * gv.y, c2 * gv.z, c2 * gv.w);
+    s1 += (gv.x * a.x + gv.y * a.y) + (gv.z * a.z + gv.w * a.w);
+    s2 += (gv.x * b.x + gv.y * b.y) + (gv.z * b.z + gv.w * b.w);
+    s3 += (gv.x * c.x + gv.y * c.y) + (gv.z * c.z + gv.w * c.w);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, OCN_WAVE); s2 += __shfl_xor(s2, o, OCN_WAVE); s3 += __shfl_xor(s3, o, OCN_WAVE); }
+  if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; sh[2][threadIdx.x >> 6] = s3; }
+  __syncthreads();
+  if (threadIdx.x < 3) part[3 * (i64)blockIdx.x + threadIdx.x] = ((sh[threadIdx.x][0] + sh[threadIdx.x][1]) + sh[threadIdx.x][2]) + sh[threadIdx.x][3];
+}
+__global__ __launch_bounds__(OCN_WAVE) void mix3_reduce_kernel(const float* __restrict__ part, float* __restrict__ dcoef) {
+  const int lane = threadIdx.x;
+  for (int k = 0; k < 3; ++k) {
+    float s = 0.f;
+    for (int b = lane; b < MIX_GROUPS; b += OCN_WAVE) s += part[3 * b + k];      // lane l: groups l, l + 64, ... in order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, OCN_WAVE);
+    if (lane == 0) dcoef[k] = s;
+  }
+}
+
 __global__ __launch_bounds__(OCN_BLOCK) void drop_mask_kernel(u64 seed, unsigned thresh, i64 n, uint8_t* __restrict__ out) {
   for (i64 q = (i64)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (i64)gridDim.x * blockDim.x)
     out[q] = (uint8_t)drop_keep(seed, (u64)q, thresh);
@@ -257,6 +296,17 @@ int ocn_ln_drop_relu_backward(const float* g, const float* x, const float* y, co
     hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3((unsigned)(2 * groups_per_vec)), dim3(LN_RED_WAVES * OCN_WAVE), 0,
                        (hipStream_t)stream, (const float*)part, (i64)LN_BWD_GROUPS, (int)H, dgamma, dbeta);
   }
+  return launch_status();
+}
+
+int64_t ocn_mix3_workspace_bytes(void) { return (int64_t)MIX_GROUPS * 3 * (int64_t)sizeof(float); }
+int ocn_mix3_backward(const float* coef, const float* g, const float* x1, const float* x2, const float* x3, int64_t n,
+                      float* d1, float* d2, float* d3, float* dcoef, void* workspace, void* stream) {
+  if (n < 0 || (n & 3)) return OCN_EINVAL;
+  if (!coef || !dcoef || !workspace || (n > 0 && (!g || !x1 || !x2 || !x3 || !d1 || !d2 || !d3))) return OCN_EINVAL;
+  hipLaunchKernelGGL(mix3_bwd_kernel, dim3(MIX_GROUPS), dim3(OCN_BLOCK), 0, (hipStream_t)stream, coef, (const float4*)g, (const float4*)x1,
+                     (const float4*)x2, (const float4*)x3, (i64)(n >> 2), (float4*)d1, (float4*)d2, (float4*)d3, (float*)workspace);
+  hipLaunchKernelGGL(mix3_reduce_kernel, dim3(1), dim3(OCN_WAVE), 0, (hipStream_t)stream, (const float*)workspace, dcoef);
   return launch_status();
 }
 

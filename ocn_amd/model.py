@@ -375,6 +375,9 @@ class _Encoder(nn.Module):
                 # eval: LayerNorm + ReLU of a layer in one HIP pass (torch's LayerNorm kernel runs at 0.26 TB/s on
                 # the 32-wide rows of the citation2 encoder: 2.9 ms per layer against 0.2 ms)
                 x1 = _seq_eval(self.lins[i], x1)
+            elif (isinstance(self.lins[i], nn.Sequential) and torch.is_grad_enabled() and x1.is_cuda and x1.dim() == 2
+                  and x1.dtype == torch.float32 and ops.train_tails):
+                x1 = _seq_train(self.lins[i], x1.contiguous())        # autograd on: the layer's LayerNorm -> Dropout -> ReLU as one launch each way
             else:
                 x1 = self.lins[i](x1)
             x = x1 + x if (self.res and x1.shape[-1] == x.shape[-1]) else x1
@@ -519,6 +522,32 @@ class _TailFn(torch.autograd.Function):
         p, seed, relu = ctx.cfg
         dx, dg, db = ops.ln_drop_relu_backward(g, x, y, stats, gamma, p, seed, relu)
         return dx, dg, db, None, None, None
+
+
+class _MixFn(torch.autograd.Function):
+    """z = coef[0] x1 + coef[1] x2 + coef[2] x3 — the branch mix of model.py:2436 / 3222 with coef = [σ(α0), σ(α0)σ(α1), β] —
+    as one launch forward (ocn_combine3) and two backward (ocn_mix3_backward: the three input gradients in one pass, the three
+    dot products <g, x_k> deterministic); the coefficients' own graph (sigmoid, cumprod) stays torch's."""
+
+    @staticmethod
+    def forward(ctx, coef, x1, x2, x3):
+        coef = coef.contiguous()
+        ctx.save_for_backward(coef, x1, x2, x3)
+        return ops.combine3(coef, x1, x2, x3)
+
+    @staticmethod
+    def backward(ctx, g):
+        coef, x1, x2, x3 = ctx.saved_tensors
+        d1, d2, d3, dc = ops.mix3_backward(coef, g, x1, x2, x3)
+        return dc, d1, d2, d3
+
+
+def _mix(alpha: Tensor, beta: Tensor, x1: Tensor, x2: Tensor, x3: Tensor) -> Tensor:
+    """alpha[0] * x1 + alpha[1] * x2 + beta * x3 (alpha = cumprod of sigmoids, already formed)."""
+    if (ops.train_tails and x1.is_cuda and x1.dtype == torch.float32 and x1.shape == x2.shape == x3.shape and x1.numel() % 4 == 0
+            and x1.is_contiguous() and x2.is_contiguous() and x3.is_contiguous()):
+        return _MixFn.apply(torch.cat([alpha[:2], beta.reshape(1)]), x1, x2, x3)
+    return alpha[0] * x1 + alpha[1] * x2 + beta * x3
 
 
 def _seq_train(seq: nn.Sequential, x: Tensor) -> Tensor:
@@ -1022,7 +1051,7 @@ class _CNPredictorBase(nn.Module):
             xij = run(self.xijlin, xij)
             xcn1 = run(self.xcn1lin, xcn1)
             xcn2 = run(self.xcn2lin, xcn2)
-            return run(self.lin, alpha[0] * xcn1 + alpha[1] * xcn2 + self.beta * xij)
+            return run(self.lin, _mix(alpha, self.beta, xcn1, xcn2, xij))
         # eval under no_grad (the drivers' test()): same modules, same parameters, on the bf16x6 MFMA
         # Linear kernel with fused LayerNorm/ReLU epilogues.  With autograd on, the torch modules
         # above run instead so that the graph is recorded.

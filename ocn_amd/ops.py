@@ -798,6 +798,25 @@ def combine3(coef: Tensor, x1: Tensor, x2: Tensor, x3: Tensor) -> Tensor:
 
 
 @_on_device
+def mix3_backward(coef: Tensor, g: Tensor, x1: Tensor, x2: Tensor, x3: Tensor):
+    """(d1, d2, d3, dcoef) of z = coef[0] x1 + coef[1] x2 + coef[2] x3 (ocn_hip.h: ocn_mix3_backward)."""
+    g = _req(g.contiguous(), torch.float32, "g")
+    for t, nm in ((x1, "x1"), (x2, "x2"), (x3, "x3")):
+        if _req(t, torch.float32, nm).shape != g.shape:
+            raise ValueError("mix3_backward: shape mismatch")
+    n = g.numel()
+    if n % 4:
+        raise ValueError("mix3_backward: n must be a multiple of 4")
+    l = _lib.lib()
+    d1, d2, d3 = torch.empty_like(g), torch.empty_like(g), torch.empty_like(g)
+    dcoef = torch.empty(3, dtype=torch.float32, device=g.device)
+    ws = torch.empty(int(l.ocn_mix3_workspace_bytes()), dtype=torch.uint8, device=g.device)
+    check(l.ocn_mix3_backward(ptr(coef), ptr(g), ptr(x1), ptr(x2), ptr(x3), n, ptr(d1), ptr(d2), ptr(d3), ptr(dcoef), ptr(ws),
+                              stream_ptr()), "ocn_mix3_backward")
+    return d1, d2, d3, dcoef
+
+
+@_on_device
 def fill_rows(dst: Tensor, vec: Tensor, row_range: Tensor) -> None:
     """dst[rows of the device-side range] = vec (dst may be a column slice of a wider buffer)."""
     _req_strided(dst, "dst")

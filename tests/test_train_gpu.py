@@ -305,3 +305,29 @@ def test_heads_tails_run_fused_under_autograd(hiplib, monkeypatch):
     c, d = run(pred, True, seed=11), run(pred, True, seed=11)
     assert not calls and torch.equal(c[0], d[0]) and torch.equal(c[1], d[1])
     assert not torch.equal(c[0], run(pred, True, seed=12)[0])                          # another seed, another mask
+
+
+@pytest.mark.parametrize("shape", [(4, 4), (1000, 64), (65536, 256), (333, 32)])
+def test_branch_mix_backward_matches_torch_autograd(hiplib, shape):
+    """ocn_mix3_backward (model._MixFn: the branch mix alpha0 a + alpha1 b + beta c under autograd): the three input gradients
+    and the three coefficient gradients against torch autograd, two runs bit-equal."""
+    from ocn_amd.model import _MixFn
+    torch.manual_seed(sum(shape))
+    xs = [torch.randn(*shape, device=DEV) for _ in range(3)]
+    coef = torch.tensor([0.7, -0.3, 1.1], device=DEV)
+    g = torch.randn(*shape, device=DEV)
+    refs = [t.clone().requires_grad_(True) for t in xs]
+    cr = coef.clone().requires_grad_(True)
+    (cr[0] * refs[0] + cr[1] * refs[1] + cr[2] * refs[2]).backward(g)
+    ins = [t.clone().requires_grad_(True) for t in xs]
+    cd = coef.clone().requires_grad_(True)
+    z = _MixFn.apply(cd, *ins)
+    assert torch.equal(z, (coef[0] * xs[0] + coef[1] * xs[1]) + coef[2] * xs[2])
+    z.backward(g)
+    for a, b in zip(ins, refs):
+        assert torch.equal(a.grad, b.grad)
+    n = g.numel()
+    assert (cd.grad - cr.grad).abs().max().item() <= 1e-5 * max(1.0, cr.grad.abs().max().item()) * (n ** 0.5) / 10
+    d = ops.mix3_backward(coef, g, *xs)
+    d2 = ops.mix3_backward(coef, g, *xs)
+    assert all(torch.equal(p, q) for p, q in zip(d, d2))

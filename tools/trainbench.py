@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--no-gc", action="store_true", help="Python's cycle collector off during the timed steps (diagnosis of step-time outliers)")
     a = ap.parse_args()
     import ocn_amd.model as M
     from ocn_amd import ops
@@ -52,6 +53,9 @@ def main():
     times, losses, mallocs = [], [], []
     it = iter(PermIterator(dev, adjmask.shape[0], B))
     for step in range(a.warmup + a.steps):
+        if a.no_gc and step == a.warmup:
+            import gc
+            gc.collect(); gc.disable()
         try:
             perm = next(it)
         except StopIteration:
