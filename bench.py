@@ -82,7 +82,7 @@ class StageTimer:
     # the stages the line's roofline objects need; the small phase-A kernels (weights, class order, schedule) are timed with
     # --all-stages only: every recorded event costs the timed region (16 marks per sampled step: -5 % on the driver's
     # 20-step run, measured; these 9: -2 %)
-    LEAN = frozenset(("begin", "cn_prep", "cn_flags", "cn_gather", "mlp_glue", "linear", "allreduce_hist"))
+    LEAN = frozenset(("begin", "cn_prep", "cn_flags", "cn_pre", "cn_gather", "mlp_glue", "linear", "allreduce_hist"))
 
     def __init__(self, pool=0, lean=True):
         self.events = []

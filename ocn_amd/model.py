@@ -676,6 +676,11 @@ class _CNPredictorBase(nn.Module):
             if ops.phase_a_extras:
                 self._class_order(st, x)           # reads the per-row counts only: off the critical phase too
                 st.prepare_schedule(x.shape[1])    # ... as does the pooling's visiting order (group costs of the intersection pass)
+                if ops.phase_a_pool and w is not None:
+                    # ... and the pooling itself: it needs the weights and the embeddings only.  Phase B is then the heads alone
+                    # (the caller's stream carried pooling + heads, 0.32 ms of kernels back to back, beside side streams with 0.2 ms
+                    # each: the pipeline's stages are better matched this way)
+                    st.pooled = self._pool(st, w, x)
         return st, handle, w
 
     def finish(self, x, token, args=None):
@@ -692,8 +697,11 @@ class _CNPredictorBase(nn.Module):
             from .dist import allreduce_hist_finish
             allreduce_hist_finish(handle)
             ops._mark("allreduce_hist")
-        w = w_early if w_early is not None else self._weights(st, args)
-        xcn1, xcn2, xij = self._pool(st, w, x)
+        pooled = getattr(st, "pooled", None)
+        if pooled is None:
+            w = w_early if w_early is not None else self._weights(st, args)
+            pooled = self._pool(st, w, x)
+        xcn1, xcn2, xij = pooled
         return self._heads(x, xcn1, xcn2, xij, getattr(st, "cls", None))
 
     def check_errors(self) -> None:

@@ -30,7 +30,7 @@ walk_share_min = 2               # walk route, B <= 4096: candidates sharing a s
 sort_edges_min_batch = 4096      # batches at least this large are processed in src order (L2 reuse of shared rows)
 heavy_first = os.environ.get("OCN_HEAVY_FIRST", "1") != "0"   # ... and the pooling (H = 256) visits its slot groups longest first (ocn_cn_flags' gcost -> ocn_gather_schedule)
 sched_segment = int(os.environ.get("OCN_SCHED_SEG", 0))        # ... inside segments of this many groups of an XCD's eighth (0 = the whole eighth)
-overlap_depth = int(os.environ.get("OCN_OVERLAP_DEPTH", 3))   # scratch sets of a predictor = the most batches a scoring loop keeps in flight
+overlap_depth = int(os.environ.get("OCN_OVERLAP_DEPTH", 4))   # scratch sets of a predictor = the most batches a scoring loop keeps in flight (round 4: four, with the pooling in phase A)
 overlap_deep_max_batch = int(os.environ.get("OCN_OVERLAP_DEEP_MAX_BATCH", 1 << 30))   # ... which it does for batches up to this size: every size by
                                  # default.  Two intersection passes beside one pooling + heads pay where phase A is the longer one: the drivers'
                                  # 2 048-candidate walk-route batches (citation2 shape 3.96 -> 4.81 M edges/s) and ANY trained cn5 model, whose
@@ -42,6 +42,11 @@ overlap_deep_max_batch = int(os.environ.get("OCN_OVERLAP_DEEP_MAX_BATCH", 1 << 3
 shard_reduce_in_finish = {"0": False, "1": True}.get(os.environ.get("OCN_REDUCE_IN_FINISH", ""), None)
 _overlap_active = False          # set by pipeline.overlapped_steps while it runs phase A on side streams
 phase_a_extras = os.environ.get("OCN_PHASE_A_EXTRAS", "1") != "0"   # unsharded loops: class ordering + pooling schedule in phase A (else phase B)
+# Unsharded loops: the POOLING runs in phase A too, so that phase B — the caller's stream — is the heads alone.  Round 3's split
+# (side streams: prep + intersection + weights, 0.2 ms of kernels each; caller's stream: pooling + heads, 0.32 ms back to back) left
+# the caller's stream the critical one; with the pooling moved and three side streams (overlap_depth 4) one box gives collab
+# 150.6 -> 158.4 M edges/s, ddi 70.3 -> 99.5 M, ppa 5.08 -> 6.05 M, citation2 4.82 -> 5.58 M, a trained cn5 model unchanged; same bits.
+phase_a_pool = os.environ.get("OCN_PHASE_A_POOL", "1") != "0"
 overlap_min_batch = 2048         # ... from this many candidates per batch (Cora-sized batches: the two event hand-offs cost more than the overlap gives)
 overlap_streams = os.environ.get("OCN_ONE_STREAM", "0") != "1"   # scoring loops: phase A of batch t + 1 on a second stream beside phase B of batch t (pipeline.overlapped_steps)
 share_full_rows = True           # cn7 on a dense graph: candidates whose whole source row is cn2 copy (A h)[source] (ocn_cn_gather `rowsum`)
@@ -471,6 +476,7 @@ def cn_gather(rowptrA, colA, src, dst, off, flags, wc: Optional[Tensor], weights
         perm = sched[n_groups:]
         if not sched_ready:           # (a scoring loop's phase A has run gather_schedule already)
             check(_lib.lib().ocn_gather_schedule(ptr(sched), n_groups, int(sched_segment), ptr(perm), stream_ptr()), "ocn_gather_schedule")
+    _mark("cn_pre")                   # (stage timers: what sits between the intersection pass and the pooling on this stream)
     check(_lib.lib().ocn_cn_gather(ptr(rowptrA), ptr(colA), ptr(src), ptr(dst), ptr(order), B, ptr(off), ptr(flags),
                                    ptr(wc), ptr(weights), ptr(h), H, int(max_row_len), ptr(out[0]), ptr(out[1]),
                                    ptr(out[2]), ptr(out_row), ptr(cnt1), ptr(cnt2), ptr(rec), ptr(perm), ptr(rowsum),

@@ -12,6 +12,7 @@ export TMPDIR=/tmp
 for C in $CFGS; do
   S=""; [ "$C" = collab ] || S="_$C"
   rm -rf $O/${R}_prof $O/${R}_pmc_fetch $O/${R}_pmc_write $O/${R}_pmc_l2 $O/${R}_pmc_mfma
+  if [ -z "$SKIP_PMC" ]; then      # (SKIP_PMC=1: bench line + kernel trace only — the per-kernel counters do not depend on the loop's stream layout)
   for P in "fetch FETCH_SIZE" "write WRITE_SIZE" "l2 TCC_HIT_sum TCC_MISS_sum" \
            "mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16"; do
     set -- $P; D=$1; shift
@@ -19,6 +20,7 @@ for C in $CFGS; do
   done
   python3 tools/pmc_summary.py $O/${R}_pmc${S}.json $O/${R}_pmc_fetch $O/${R}_pmc_write $O/${R}_pmc_l2 $O/${R}_pmc_mfma
   cp $O/${R}_pmc${S}.json profiles/${R}_pmc${S}.json
+  fi
   timeout -k 10 500 python3 bench.py --config $C > $O/${R}_bench_${C}.json 2> $O/${R}_bench_${C}.err
   # the kernel trace is taken on the DRIVER's command shape (20 steps, 5 warm-up) without the serialised-streams leg, so that
   # its per-kernel averages are over the overlapped loop the line's own stage events sample
