@@ -470,6 +470,11 @@ def main():
     def timed_loop(steps, timer, overlap=None):
         """EXACTLY `steps` steps between two barrier + synchronize brackets; returns (seconds, host enqueue seconds)."""
         ops.stage_timer = timer
+        # Python's cycle collector stays out of the timed region: a generation-2 pass over a process that holds a few hundred
+        # thousand torch objects is a 50 - 150 ms pause (measured in the training loop, DESIGN.md §6) — several times a 13 ms region
+        import gc
+        gc.collect()
+        gc.disable()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -528,6 +533,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        gc.enable()
         ops.stage_timer = None
         if world > 1:
             tmax = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -651,7 +651,7 @@ class _CNPredictorBase(nn.Module):
         must not share buffers with the ones still in flight) and, sharded, the START of the histogram sum.  Returns a token."""
         if self.training or torch.is_grad_enabled():
             raise RuntimeError("begin / finish is the no-grad scoring path: call .eval() under torch.no_grad()")
-        n_sets = max(2, int(ops.overlap_depth))
+        n_sets = max(2, int(ops.overlap_depth), int(ops.overlap_depth_small))
         if len(getattr(self, "_ws_slots", ())) != n_sets:
             self._ws_slots = [dict() for _ in range(n_sets)]
         st = fuse(cn1, cn2, tar_ei, self._ws_slots[slot % n_sets], adj=adj)

@@ -31,6 +31,8 @@ sort_edges_min_batch = 4096      # batches at least this large are processed in 
 heavy_first = os.environ.get("OCN_HEAVY_FIRST", "1") != "0"   # ... and the pooling (H = 256) visits its slot groups longest first (ocn_cn_flags' gcost -> ocn_gather_schedule)
 sched_segment = int(os.environ.get("OCN_SCHED_SEG", 0))        # ... inside segments of this many groups of an XCD's eighth (0 = the whole eighth)
 overlap_depth = int(os.environ.get("OCN_OVERLAP_DEPTH", 4))   # scratch sets of a predictor = the most batches a scoring loop keeps in flight (round 4: four, with the pooling in phase A)
+overlap_depth_small = int(os.environ.get("OCN_OVERLAP_DEPTH_SMALL", 8))   # ... and for batches of at most overlap_small_batch candidates (the drivers' 2 048: latency chains, not bandwidth — citation2 shape 5.58 -> 5.83 M edges/s, ppa unchanged)
+overlap_small_batch = 4096
 overlap_deep_max_batch = int(os.environ.get("OCN_OVERLAP_DEEP_MAX_BATCH", 1 << 30))   # ... which it does for batches up to this size: every size by
                                  # default.  Two intersection passes beside one pooling + heads pay where phase A is the longer one: the drivers'
                                  # 2 048-candidate walk-route batches (citation2 shape 3.96 -> 4.81 M edges/s) and ANY trained cn5 model, whose
@@ -51,6 +53,13 @@ overlap_min_batch = 2048         # ... from this many candidates per batch (Cora
 overlap_streams = os.environ.get("OCN_ONE_STREAM", "0") != "1"   # scoring loops: phase A of batch t + 1 on a second stream beside phase B of batch t (pipeline.overlapped_steps)
 share_full_rows = True           # cn7 on a dense graph: candidates whose whole source row is cn2 copy (A h)[source] (ocn_cn_gather `rowsum`)
 deterministic_backward = os.environ.get("OCN_ATOMIC_BACKWARD", "0") != "1"   # pooling backward node by node in a fixed order (ocn_cn_gather_backward_det); else fp32 atomics
+
+
+def loop_depth(batch) -> int:
+    """Batches a scoring loop keeps in flight (= streams it uses) for batches of this size (None: unknown -> two)."""
+    if batch is None or batch > overlap_deep_max_batch:
+        return 2
+    return max(2, int(overlap_depth_small if batch <= overlap_small_batch else overlap_depth))
 
 
 def _on_device(fn):

@@ -171,7 +171,7 @@ def overlapped_steps(begin, finish, n_steps: int, before_step=None, after_step=N
     # ops._on_device — so the loop's main stream, side streams and events are that device's, whatever the current device is)
     main = torch.cuda.current_stream(index)
     # batches in flight: depth - 1 in phase A, one in phase B
-    depth = max(2, int(ops.overlap_depth)) if (batch is not None and batch <= ops.overlap_deep_max_batch) else 2
+    depth = ops.loop_depth(batch)
     sides = [_side_stream(index, q) for q in range(depth - 1)]
     begun = [torch.cuda.Event() for _ in range(depth)]
     done = [torch.cuda.Event() for _ in range(depth)]
@@ -231,7 +231,7 @@ def pipelined_shard_loop(begin, finish, n_steps: int, batch_total: int, group=No
         overlap = (bool(ops.overlap_streams) and torch.cuda.is_available() and torch.cuda.is_initialized()
                    and batch_total // max(world, 1) >= ops.overlap_min_batch)
     if overlap:
-        deep = max(2, int(ops.overlap_depth)) if batch_total // max(world, 1) <= ops.overlap_deep_max_batch else 2
+        deep = ops.loop_depth(batch_total // max(world, 1))
         streams = ("; phase A (intersection pass) of batch t + 1 on a second HIP stream beside phase B of batch t" if deep == 2 else
                    f"; phase A (intersection pass) of batches t + 1 .. t + {deep - 1} on {deep - 1} more HIP streams beside phase B of batch t")
     it = -1
