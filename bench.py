@@ -349,6 +349,7 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N > 1: weak = `batch` candidates PER RANK of a global batch of N x batch (the default line); strong = the "
                          "reference's ONE batch (collab: 65 536 edges) cut N ways, north_star's 'partition the edge batch across the GPUs'")
+    ap.add_argument("--no-graph-loops", action="store_true", help="N = 1: enqueue every step launch by launch (no HIP-graph replay of the phases)")
     ap.add_argument("--no-one-stream-leg", action="store_true",
                     help="skip the untimed pass with the streams serialised (the *_one_stream keys): a kernel trace of the command "
                          "then averages over the overlapped loop only, like the line's own stage events")
@@ -406,10 +407,27 @@ def main():
     pipelined = not args.graph                     # N = 1 too: phase A of batch t + 1 runs on a second stream beside phase B of batch t
     ahead = [None, -1]                             # [token of the batch already begun, its index]
 
+    # N = 1: the library's loops replay phase A / phase B of a scratch set as captured HIP graphs (pipeline.GraphedPhases: the host
+    # side of a step, ~25 ctypes launches, becomes one id copy and two graph launches); steps whose stages are being timed run
+    # launch by launch.  A new set of graphs whenever the predictor's state changes what is launched (the trained-innerprod leg).
+    use_graphs = (world == 1 and not args.rehearse_collectives and not args.no_graph_loops and not args.graph and ops.graph_loops)
+    graphed = [None]
+
+    def new_graphs():
+        from ocn_amd.pipeline import GraphedPhases
+        graphed[0] = GraphedPhases(pred, h, adj, lambda e: cn_handles(wl, e), mines[0].shape[1], wl["args"]) if use_graphs else None
+
     def begin(it):
         mine = mines[it % NB]
+        if graphed[0] is not None:
+            return graphed[0].begin(it, mine)
         c1, c2 = cn_handles(wl, mine)
         return pred.begin(h, adj, c1, c2, mine, slot=it, args=wl["args"])
+
+    def finish(tok):
+        if graphed[0] is not None:
+            return graphed[0].finish(tok).clone()            # (a replay's scores live in the graph's pool until the set's next batch)
+        return pred.finish(h, tok, wl["args"])
 
     def step(it=0, last=True):
         with torch.no_grad():
@@ -447,11 +465,12 @@ def main():
     # Runtime pre-warm (untimed, before the W warm-up steps): the HIP runtime grows its internal
     # command/signal pools in ~35 ms host stalls during the first ~1000 launches of a process; a short
     # --warmup would otherwise put one of them inside the timed region.
+    new_graphs()
     if pipelined and args.prewarm > 0:             # (on the timed loop's own code path too: what a kernel trace of this command averages
         from ocn_amd.pipeline import pipelined_shard_loop           # over is then the overlapped loop, not a one-stream variant of it)
         with torch.no_grad():
             for _ in range(max(args.prewarm // 16, 1)):
-                pipelined_shard_loop(begin, lambda tok: pred.finish(h, tok, wl["args"]), 16, B_total, gather_at_end=True)
+                pipelined_shard_loop(begin, finish, 16, B_total, gather_at_end=True)
                 torch.cuda.synchronize()
     else:
         for i in range(args.prewarm):
@@ -461,7 +480,7 @@ def main():
     if pipelined and args.warmup > 0:              # the W warm-up steps run the timed loop's own code path (second stream included)
         from ocn_amd.pipeline import pipelined_shard_loop
         with torch.no_grad():
-            pipelined_shard_loop(begin, lambda tok: pred.finish(h, tok, wl["args"]), args.warmup, B_total, gather_at_end=True)
+            pipelined_shard_loop(begin, finish, args.warmup, B_total, gather_at_end=True)
         torch.cuda.synchronize()
     else:
         for i in range(args.warmup):
@@ -512,7 +531,7 @@ def main():
             # rank keeps its slices, ONE all-gather closes the loop inside the timed region
             from ocn_amd.pipeline import pipelined_shard_loop
             with torch.no_grad():
-                scores, pattern[0] = pipelined_shard_loop(begin, lambda tok: pred.finish(h, tok, wl["args"]), steps, B_total,
+                scores, pattern[0] = pipelined_shard_loop(begin, finish, steps, B_total,
                                                           gather_at_end=True, before_step=before_step, after_step=after_step,
                                                           overlap=overlap)
             out = scores[-1]
@@ -561,6 +580,7 @@ def main():
     # second leg: the per-batch id check left on (the drivers' literal loop: one host sync per batch)
     dt_val = None
     if not args.no_validate_leg and not args.graph:
+        graphed[0] = None                          # (the per-batch id check is a host sync inside begin(): launch by launch)
         ops.validate_indices = True
         for i in range(4):
             step(i)
@@ -577,12 +597,18 @@ def main():
             pred.innerprod.fill_(0.37)
         for i in range(4):
             step(i)
+        new_graphs()
+        if graphed[0] is not None:                 # (two eager uses and the capture of every scratch set, untimed)
+            from ocn_amd.pipeline import pipelined_shard_loop
+            with torch.no_grad():
+                pipelined_shard_loop(begin, finish, 4 * graphed[0].n_sets, B_total, gather_at_end=True)
         n_tr = min(args.steps, 64)
         dt_tr, _, _ = timed_loop(n_tr, None)
         dt_tr /= n_tr
         with torch.no_grad():
             pred.innerprod.fill_(0.0)
         step(0)
+        graphed[0] = None
 
     if rank == 0:
         per = [batch_bytes(wl, m, H) for m in mines]

@@ -49,6 +49,12 @@ phase_a_extras = os.environ.get("OCN_PHASE_A_EXTRAS", "1") != "0"   # unsharded 
 # the caller's stream the critical one; with the pooling moved and three side streams (overlap_depth 4) one box gives collab
 # 150.6 -> 158.4 M edges/s, ddi 70.3 -> 99.5 M, ppa 5.08 -> 6.05 M, citation2 4.82 -> 5.58 M, a trained cn5 model unchanged; same bits.
 phase_a_pool = os.environ.get("OCN_PHASE_A_POOL", "1") != "0"
+# Scoring loops: phase A / phase B of a scratch set as captured HIP graphs (pipeline.GraphedPhases).  OFF by default: measured on one
+# box, the host's enqueue time per step drops 0.26 -> 0.07 ms (ddi / ppa / citation2 shapes; collab 0.20 -> 0.08) and the
+# throughput does not move (ddi 97.0 vs 97.8 M edges/s, ppa 5.5 - 6.0 vs 6.0, citation2 5.8 vs 5.6 - 5.8, collab 155.5 both): the
+# steps are bound on the device, as round 3 found for the one-stream capture.  For a caller whose host has other work to do.
+graph_loops = os.environ.get("OCN_GRAPH_LOOPS", "0") == "1"
+graph_loops_min_batches_per_set = 6                                # ... from this many batches per scratch set on (two eager uses + one capture each)
 overlap_min_batch = 2048         # ... from this many candidates per batch (Cora-sized batches: the two event hand-offs cost more than the overlap gives)
 overlap_streams = os.environ.get("OCN_ONE_STREAM", "0") != "1"   # scoring loops: phase A of batch t + 1 on a second stream beside phase B of batch t (pipeline.overlapped_steps)
 share_full_rows = True           # cn7 on a dense graph: candidates whose whole source row is cn2 copy (A h)[source] (ocn_cn_gather `rowsum`)

@@ -185,3 +185,46 @@ def test_poisoned_offsets_raise_the_sticky_status_and_orders_fall_back(hiplib):
     # (3) CNState.check_status names the bit
     st = CNState(adj, adj, adj2, e)
     st.check_status()
+
+
+@pytest.mark.parametrize("route", ["pattern", "walk"])
+def test_graph_replayed_scoring_loop_equals_the_eager_loop(hiplib, monkeypatch, route):
+    """pipeline.GraphedPhases: after two eager uses of a scratch set, phase A (prep .. pooling) and phase B (heads) of its
+    batches are captured HIP graphs replayed with a fresh copy of the candidate ids.  Scores of a split of 70 batches (ragged
+    tail included) equal the launch-by-launch loop bit for bit, on both CN routes; graphs were actually captured."""
+    from ocn_amd import ops, pipeline
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.pipeline import score_edges, score_mrr_split
+    n, H, bs = 3000, 64, 256
+    oadj = make_graph(n, 14, 300, seed=21)
+    adj = to_product(oadj, DEV)
+    adj2 = product_adj2(adj)
+    monkeypatch.setattr(ops, "overlap_min_batch", 0)
+    torch.manual_seed(3)
+    x = torch.randn(n, H, device=DEV)
+    name = "cn5" if route == "pattern" else "cn7"
+    pred = predictor_dict[name](H, H, 1, 3, 0.0, 0.0, True).to(DEV).eval()
+    args = SimpleNamespace(sum=0.5)
+    e = batch(oadj, 70 * bs - 19, 5).to(DEV)
+    made = []
+    orig = pipeline.GraphedPhases.finish
+
+    def spy(self, token):
+        made.append(token[0])
+        return orig(self, token)
+    monkeypatch.setattr(pipeline.GraphedPhases, "finish", spy)
+
+    def run():
+        with torch.no_grad():
+            if route == "pattern":
+                return score_edges(pred, x, adj, adj2, e.t().contiguous(), bs, args)
+            neg = torch.randint(0, n, (e.shape[1], 1), generator=torch.Generator().manual_seed(1)).to(DEV)
+            pos, negp = score_mrr_split(pred, x, adj, e[0].contiguous(), e[1].contiguous(), neg, bs, args)
+            return torch.cat([pos, negp.reshape(-1)])
+    monkeypatch.setattr(ops, "graph_loops", True)
+    got = run()
+    assert made.count("graph") > 20 and "eager" in made
+    monkeypatch.setattr(ops, "graph_loops", False)
+    ref = run()
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
