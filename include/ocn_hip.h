@@ -33,8 +33,9 @@ extern "C" {
  *    ocn_cn_gather gains `perm` and `rowsum`.
  * 8: a scan whose workspace was not zero ends in OCN_SCAN_POISON totals and a status bit instead of a GPU trap; `status` is
  *    int32[4] for every intersection entry, word 3 the sticky error word; ocn_cn_weights_cn7 takes the Chebyshev diagonals,
- *    ocn_gather_schedule a segment; + ocn_cn_gather3_backward, ocn_cn_gather_backward_det_lists, ocn_ln_drop_relu_*. */
-#define OCN_ABI_VERSION 8
+ *    ocn_gather_schedule a segment; + ocn_cn_gather3_backward, ocn_cn_gather_backward_det_lists, ocn_ln_drop_relu_*.
+ * 9: + ocn_heads_small_batch (ocn_heads_fused picks its small-batch form by the batch size; same bits). */
+#define OCN_ABI_VERSION 9
 #define OCN_EINVAL (-1)   /* null pointer / negative size / unsupported combination */
 #define OCN_ECAP   (-2)   /* reported through the device status word: flags capacity too small */
 
@@ -499,6 +500,11 @@ int64_t ocn_heads_const_bytes(int32_t H);
 int64_t ocn_heads_panel_bytes(int32_t N, int32_t K);
 int ocn_heads_split_weight(const float* W, int32_t N, int32_t K, float scale, void* Wp, void* stream);
 int ocn_heads_fused(const OcnHeadsArgs* args, void* stream);
+/* Batches of up to `max_rows` candidates are scored by the small-batch form of the same head — 32 candidates per workgroup,
+ * the four waves splitting every layer's output features — which returns the same bits as the throughput form at a fifth of
+ * its latency (Cora's 1 152-candidate batch: nine 128-row tiles = 70 us whatever the batch size).  Sets the bound (process-wide;
+ * default 16384 = two rounds of workgroups on 256 CUs) and returns the previous one; a negative argument only queries. */
+int64_t ocn_heads_small_batch(int64_t max_rows);
 
 /* Training-side pieces (NeighborOverlap_large.py:56-63, 76-90).
  *

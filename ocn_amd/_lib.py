@@ -19,7 +19,7 @@ INCLUDE = os.path.join(_ROOT, "include")
 
 # name -> (restype, argtypes); must list every symbol include/ocn_hip.h declares
 _P = c_void_p
-ABI_VERSION = 8
+ABI_VERSION = 9
 SIGNATURES = {
     "ocn_abi_version": (c_int32, []),
     "ocn_scan_workspace_bytes": (c_int64, [c_int64]),
@@ -95,6 +95,7 @@ SIGNATURES = {
     "ocn_heads_panel_bytes": (c_int64, [c_int32, c_int32]),
     "ocn_heads_split_weight": (c_int32, [_P, c_int32, c_int32, c_float, _P, _P]),
     "ocn_heads_fused": (c_int32, [_P, _P]),
+    "ocn_heads_small_batch": (c_int64, [c_int64]),
 }
 
 

@@ -196,9 +196,19 @@ __device__ __forceinline__ float hd_max4(float m, f32x4 v) { return fmaxf(fmaxf(
 __device__ __forceinline__ f32x4 hd_grp(const f32x16& v, int g) { return f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}; }
 #define HD_GRP(v, g) hd_grp(v, g)
 
+// A sum over a candidate's H features is formed as four quarter sums — tiles [w NT/4, (w + 1) NT/4), the features one wave of
+// heads_nsplit_kernel owns — each a sequential f32x4 chain folded (p0 + p1) + (p2 + p3) and joined with the other half-lane,
+// then (P0 + P1) + (P2 + P3): the order both forms of the head share.
+__device__ __forceinline__ float hd_quarter(const f32x4& p) {
+  const float P = (p[0] + p[1]) + (p[2] + p[3]);
+  return P + __shfl_xor(P, 32, OCN_WAVE);
+}
+__device__ __forceinline__ float hd_quad(const float (&P)[4]) { return (P[0] + P[1]) + (P[2] + P[3]); }
+
 template <int NT>
 struct Heads {
   static constexpr int H = 32 * NT;
+  static constexpr int TQ = NT / 4;                        // tiles per quarter sum
   static constexpr int KS = 2 * NT;                        // k-steps per layer
   static constexpr int TPC = 2 * NT;                       // output tiles per chunk (two k-steps)
   static constexpr int NCH = NT;                           // chunks per layer
@@ -336,29 +346,34 @@ struct Heads {
   // 16 NT registers of lanes r, r + 32); returns the lane's largest result
   static __device__ __forceinline__ float bias_ln_relu(In& in, Acc& acc, float inv, const float* v, const float* gm, const float* bt,
                                                        float eps, int hh) {
-    f32x4 s4 = (f32x4)(0.f);
+    float P[4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int w = 0; w < 4; ++w) {
+      f32x4 s4 = (f32x4)(0.f);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 y = __builtin_elementwise_fma(HD_GRP(acc[t], g), (f32x4)(inv), hd_lds4(v + 32 * t + 8 * g + 4 * hh));
-        s4 += y;
-        in[4 * t + g] = y;
-        if (g == 3) next_tile(in, acc, t);
-      }
-    float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-    s += __shfl_xor(s, 32, OCN_WAVE);
-    const float nmean = -(s * (1.0f / (float)H));
-    f32x4 q4 = (f32x4)(0.f);
+      for (int t = w * TQ; t < (w + 1) * TQ; ++t)
 #pragma unroll
-    for (int t = 0; t < 4 * NT; ++t) {
-      const f32x4 d = in[t] + (f32x4)(nmean);
-      q4 = __builtin_elementwise_fma(d, d, q4);
-      in[t] = d;
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 y = __builtin_elementwise_fma(HD_GRP(acc[t], g), (f32x4)(inv), hd_lds4(v + 32 * t + 8 * g + 4 * hh));
+          s4 += y;
+          in[4 * t + g] = y;
+          if (g == 3) next_tile(in, acc, t);
+        }
+      P[w] = hd_quarter(s4);
     }
-    float q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
-    q += __shfl_xor(q, 32, OCN_WAVE);
-    const float rstd = rsqrtf(q * (1.0f / (float)H) + eps);
+    const float nmean = -(hd_quad(P) * (1.0f / (float)H));
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      f32x4 q4 = (f32x4)(0.f);
+#pragma unroll
+      for (int t = 4 * w * TQ; t < 4 * (w + 1) * TQ; ++t) {
+        const f32x4 d = in[t] + (f32x4)(nmean);
+        q4 = __builtin_elementwise_fma(d, d, q4);
+        in[t] = d;
+      }
+      P[w] = hd_quarter(q4);
+    }
+    const float rstd = rsqrtf(hd_quad(P) * (1.0f / (float)H) + eps);
     float m = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -557,6 +572,7 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
       HD_STAMP(19);
     }
     // ---- lin: LayerNorm, ReLU, Linear(H, 1) on the accumulator file (the VGPR set already holds the next rows) -----
+    float PS[4];                          // quarter sums of the last layer's input (hd_quad)
     f32x4 s4 = (f32x4)(0.f);
     {
       // ((share a + share b) + share c) + folded bias; a skipped branch's share is its constant
@@ -594,47 +610,55 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
         rB[t] = o;
         if (t + 1 < NT) asm volatile("" : "+a"(rB[t]), "+a"(rB[t + 1]));
         else asm volatile("" : "+a"(rB[t]));
+        if ((t + 1) % HD::TQ == 0) { PS[t / HD::TQ] = hd_quarter(s4); s4 = (f32x4)(0.f); }
       }
     }
-    float d = 0.f;
+    constexpr int TQ = HD::TQ;
+    float PD4[4];                         // quarter sums of the dot product
     const float* dw = s_vec + V_DOTW * H;
     if constexpr (LN) {
-      float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-      s += __shfl_xor(s, 32, OCN_WAVE);
-      const float nmean = -(s * (1.0f / (float)H));
-      f32x4 q4 = (f32x4)(0.f);
+      const float nmean = -(hd_quad(PS) * (1.0f / (float)H));
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int w4 = 0; w4 < 4; ++w4) {
+        f32x4 q4 = (f32x4)(0.f);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 dd = HD_GRP(rB[t], g) + (f32x4)(nmean);
-          q4 = __builtin_elementwise_fma(dd, dd, q4);
-        }
-      float q = (q4[0] + q4[1]) + (q4[2] + q4[3]);
-      q += __shfl_xor(q, 32, OCN_WAVE);
-      const float rstd = rsqrtf(q * (1.0f / (float)H) + a.eps);
-      f32x4 d4 = (f32x4)(0.f);
+        for (int t = w4 * TQ; t < (w4 + 1) * TQ; ++t)
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 dd = HD_GRP(rB[t], g) + (f32x4)(nmean);
+            q4 = __builtin_elementwise_fma(dd, dd, q4);
+          }
+        PS[w4] = hd_quarter(q4);
+      }
+      const float rstd = rsqrtf(hd_quad(PS) * (1.0f / (float)H) + a.eps);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int fo = 32 * t + 8 * g + 4 * hh;
-          f32x4 y = __builtin_elementwise_fma((HD_GRP(rB[t], g) + (f32x4)(nmean)) * (f32x4)(rstd), hd_lds4(s_vec + V_GL * H + fo),
-                                              hd_lds4(s_vec + V_EL * H + fo));
-          y = __builtin_elementwise_max(y, (f32x4)(0.f));
-          d4 = __builtin_elementwise_fma(y, hd_lds4(dw + fo), d4);
-        }
-      d = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+      for (int w4 = 0; w4 < 4; ++w4) {
+        f32x4 d4 = (f32x4)(0.f);
+#pragma unroll
+        for (int t = w4 * TQ; t < (w4 + 1) * TQ; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int fo = 32 * t + 8 * g + 4 * hh;
+            f32x4 y = __builtin_elementwise_fma((HD_GRP(rB[t], g) + (f32x4)(nmean)) * (f32x4)(rstd), hd_lds4(s_vec + V_GL * H + fo),
+                                                hd_lds4(s_vec + V_EL * H + fo));
+            y = __builtin_elementwise_max(y, (f32x4)(0.f));
+            d4 = __builtin_elementwise_fma(y, hd_lds4(dw + fo), d4);
+          }
+        PD4[w4] = hd_quarter(d4);
+      }
     } else {
-      f32x4 d4 = (f32x4)(0.f);
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int w4 = 0; w4 < 4; ++w4) {
+        f32x4 d4 = (f32x4)(0.f);
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          d4 = __builtin_elementwise_fma(__builtin_elementwise_max(HD_GRP(rB[t], g), (f32x4)(0.f)), hd_lds4(dw + 32 * t + 8 * g + 4 * hh), d4);
-      d = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+        for (int t = w4 * TQ; t < (w4 + 1) * TQ; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            d4 = __builtin_elementwise_fma(__builtin_elementwise_max(HD_GRP(rB[t], g), (f32x4)(0.f)), hd_lds4(dw + 32 * t + 8 * g + 4 * hh), d4);
+        PD4[w4] = hd_quarter(d4);
+      }
     }
-    d += __shfl_xor(d, 32, OCN_WAVE);
+    const float d = hd_quad(PD4);
     if (live && hh == 0 && !a.dump) a.y[a.y_row_map ? a.y_row_map[slot] : slot] = d + s_scal[0];
     HD_STAMP(20);
   }
@@ -644,6 +668,340 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
     if (blockIdx.x < 192) { o[0] = __builtin_amdgcn_s_memtime() - clk0; o[1] = __builtin_amdgcn_s_memrealtime() - rt0; }
   }
 #endif
+}
+
+// ---- small batches: the same head on a tile of 32 candidates per workgroup (latency instead of throughput) -------------
+// heads_fused_kernel walks a candidate through eight layers on ONE wave: 8 x (12 288 matrix-pipe cycles + epilogue) = 70 us
+// whatever the batch size — Cora's whole 1 152-candidate batch is nine such tiles on nine CUs.  Here the four waves of a
+// workgroup share 32 candidates and split the OUTPUT features of every layer: wave w owns accumulator tiles w NT/4 ...,
+// a quarter of the k-loop's MFMAs, and a quarter of every epilogue.  What the next layer needs of a finished one is its B
+// operand: a lane's eight f16 pairs of k-step (t, ss) are the split of the SAME lane's accumulator registers 8 ss .. 8 ss + 7 of
+// tile t, so the wave that owns tile t splits its results once and stores both fragments where all four waves read them —
+// the operand buffer [k-step][hi, lo][lane], 2 NT KiB of LDS; no wave holds a whole activation row.  Row maxima (the scale)
+// and the LayerNorm sums cross the waves through three small LDS arrays.  A weight fragment is used by exactly one wave of
+// the workgroup: L2 -> registers, PD k-steps ahead (no LDS ring, no LDS-DMA).
+// The arithmetic is heads_fused_kernel's, operation for operation — same panels, same k order, same split, same row scales,
+// the sums over a row's features as four quarter sums combined (P0 + P1) + (P2 + P3) in both kernels (hd_quad) — so the two
+// return the same BITS (tests/test_parity_gpu.py::test_heads_small_batch_kernel_is_bit_equal); a tile none of whose
+// candidates has a branch's input takes the branch's constant from cpark, as there.
+template <int NT>
+struct HeadsN {
+  using HD = Heads<NT>;
+  static constexpr int H = 32 * NT, KS = HD::KS, TW = NT / 4, PD = 8, ROWS = 32;
+  static constexpr int OB_VECS = KS * 2 * 64;                                   // the operand buffer, in 16-byte fragments per lane
+  static constexpr int RED_FLOATS = 3 * 4 * 64;                                 // sums, squares / dot, maxima: [wave][lane]
+  static constexpr size_t LDS_BYTES = (size_t)HD::LDS_W + (size_t)OB_VECS * 16 + (size_t)RED_FLOATS * 4;
+  typedef h16x8 Frag[PD][TW][2];
+  typedef f32x16 Acc[TW];
+  typedef f32x4 Own[TW][4];            // this wave's part of a layer's output: [u][g][j] = feature 32 (w TW + u) + 8 g + 4 hh + j
+  typedef const __attribute__((address_space(1))) h16x8* panel_t;
+  static_assert(PD <= KS && KS % PD == 0, "prefetch ring");
+
+  // The fragments (hi, lo) of k-step s for this wave's tiles: panel + vo + s NT 2 KiB, vo = (w TW 2) KiB + 16 lane.  Requested by
+  // hand and waited for by count (wait<>): left to the compiler, the requests of a prefetch ring this deep sink down to their
+  // uses — one L2 round trip per k-step.  Vector-memory operations complete in order, so "at most N outstanding" means the
+  // N youngest; requests the compiler makes itself only make a count stricter than needed.
+  template <int IMM>
+  static __device__ __forceinline__ void gload(h16x8& f, unsigned vo, const char* panel) {
+    static_assert(IMM >= 0 && IMM < 4096, "global offset");
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(f) : "v"(vo), "s"(panel), "i"(IMM));      // (read-only data: no memory clobber, LDS reads may pass)
+  }
+  template <int S>
+  static __device__ __forceinline__ void fetch(Frag& f, unsigned vo, const char* panel) {
+    const unsigned v = vo + (unsigned)(S * NT * 2048);
+    hd_unroll<TW>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      gload<u * 2048>(f[S % PD][u][0], v, panel);
+      gload<u * 2048 + 1024>(f[S % PD][u][1], v, panel);
+    });
+  }
+  template <int N, int K>
+  static __device__ __forceinline__ void wait(Frag& f) {
+    if constexpr (TW == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(f[K][0][0]), "+v"(f[K][0][1]), "+v"(f[K][1][0]), "+v"(f[K][1][1]) : "i"(N));
+    else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f[K][0][0]), "+v"(f[K][0][1]) : "i"(N));
+  }
+
+  // acc = (this wave's rows of Wp) . (the operand buffer); the fragments of the first PD k-steps are on their way, the layer
+  // leaves those of the next panel so
+  template <bool LAST>
+  static __device__ __forceinline__ void layer(Acc& acc, const h16x8* ob /* + lane */, Frag& f, unsigned vo, const char* p_cur, const char* p_nxt) {
+    h16x8 bq[2][2] = {{ob[0], ob[64]}, {}};                                              // the B operand, one k-step ahead
+    hd_unroll<KS>([&](auto sc_) {
+      constexpr int s = decltype(sc_)::value, k = s % PD;
+      constexpr int ahead = (LAST && KS - 1 - s < PD - 1) ? KS - 1 - s : PD - 1;       // k-steps requested after this one
+      if constexpr (s + 1 < KS) { bq[(s + 1) & 1][0] = ob[(2 * s + 2) * 64]; bq[(s + 1) & 1][1] = ob[(2 * s + 3) * 64]; }
+      const h16x8 bh = bq[s & 1][0], bl = bq[s & 1][1];
+      wait<ahead * 2 * TW, k>(f);
+#pragma unroll
+      for (int u = 0; u < TW; ++u) {
+        if constexpr (s == 0) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k][u][0], bl, (f32x16)(0.f), 0, 0, 0);     // wh . xl
+        else acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k][u][0], bl, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k][u][1], bh, acc[u], 0, 0, 0);                                  // wl . xh
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k][u][0], bh, acc[u], 0, 0, 0);                                  // wh . xh
+      }
+      // the ring slot is free once its MFMAs have read it: the request is issued behind them in program order, and a load's
+      // write-back cannot pass an earlier instruction's operand read
+      if constexpr (s + PD < KS) { pin(acc); fetch<s + PD>(f, vo, p_cur); }
+      else if constexpr (!LAST) { pin(acc); fetch<s + PD - KS + 0>(f, vo, p_nxt); }
+    });
+  }
+  static __device__ __forceinline__ void pin(Acc& acc) {
+#pragma unroll
+    for (int u = 0; u < TW; ++u) asm volatile("" : "+a"(acc[u]));
+  }
+
+  // (R0 + R1) + (R2 + R3) of the four waves' values of this lane: `mine` goes to red[w][lane], everybody reads all four
+  static __device__ __forceinline__ void cross_put(float* red, float mine, int w, int lane) { red[w * 64 + lane] = mine; }
+  static __device__ __forceinline__ float cross_sum(const float* red, int lane) {
+    return (red[lane] + red[64 + lane]) + (red[128 + lane] + red[192 + lane]);
+  }
+  static __device__ __forceinline__ float cross_max(const float* red, int lane) {
+    return fmaxf(fmaxf(red[lane], red[64 + lane]), fmaxf(red[128 + lane], red[192 + lane]));
+  }
+  static __device__ __forceinline__ float quarter(const f32x4& p) { return hd_quarter(p); }      // this wave's P_w of hd_quad
+
+  // y = acc * inv + v[feature] (ReLU) on this wave's tiles
+  template <bool RELU>
+  static __device__ __forceinline__ void bias(Own& y, Acc& acc, float inv, const float* v, int w, int hh) {
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        y[u][g] = __builtin_elementwise_fma(HD_GRP(acc[u], g), (f32x4)(inv), hd_lds4(v + 32 * (w * TW + u) + 8 * g + 4 * hh));
+        if constexpr (RELU) y[u][g] = __builtin_elementwise_max(y[u][g], (f32x4)(0.f));
+      }
+  }
+  // y = ReLU(LayerNorm(y)) over the whole row (two crossings); Heads::bias_ln_relu's arithmetic
+  static __device__ __forceinline__ void ln_relu(Own& y, const float* gm, const float* bt, float eps, float* red, int w, int hh, int lane) {
+    f32x4 s4 = (f32x4)(0.f);
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) s4 += y[u][g];
+    cross_put(red, quarter(s4), w, lane);
+    __syncthreads();
+    const float nmean = -(cross_sum(red, lane) * (1.0f / (float)H));
+    f32x4 q4 = (f32x4)(0.f);
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 d = y[u][g] + (f32x4)(nmean);
+        q4 = __builtin_elementwise_fma(d, d, q4);
+        y[u][g] = d;
+      }
+    cross_put(red + 256, quarter(q4), w, lane);
+    __syncthreads();
+    const float rstd = rsqrtf(cross_sum(red + 256, lane) * (1.0f / (float)H) + eps);
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fo = 32 * (w * TW + u) + 8 * g + 4 * hh;
+        y[u][g] = __builtin_elementwise_max(__builtin_elementwise_fma(y[u][g] * (f32x4)(rstd), hd_lds4(gm + fo), hd_lds4(bt + fo)), (f32x4)(0.f));
+      }
+  }
+  // the next layer's B operand from this layer's output: the row's scale (one crossing), this wave's values split and stored;
+  // ABS: raw inputs (any sign) instead of ReLU outputs.  The closing barrier also ends the previous k-loop's reads of `ob`:
+  // every wave is past it before the first store below (the crossing's barrier stands between).
+  template <bool ABS>
+  static __device__ __forceinline__ void operand(h16x8* ob /* + lane */, Own& y, float pinv, float& inv, float* red, int w, int lane) {
+    float m = 0.f;
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) m = hd_max4(m, ABS ? __builtin_elementwise_abs(y[u][g]) : y[u][g]);
+    cross_put(red + 512, m, w, lane);
+    __syncthreads();
+    float sc;
+    hd_row_scale(cross_max(red + 512, lane), pinv, sc, inv);
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        unsigned xh[4], xl[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) hd_split(y[u][2 * ss + (p >> 1)][2 * (p & 1)], y[u][2 * ss + (p >> 1)][2 * (p & 1) + 1], sc, xh[p], xl[p]);
+        const int s = 2 * (w * TW + u) + ss;
+        ob[(2 * s) * 64] = hd_frag(xh);
+        ob[(2 * s + 1) * 64] = hd_frag(xl);
+      }
+    __syncthreads();
+  }
+};
+
+#ifdef OCN_X_HN_STAMPS               /* diagnostic build only (tools/headslat.py -DOCN_X_HN_STAMPS): s_memtime at the phase boundaries of workgroup 0, wave 0 */
+#define HN_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) \
+    reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.scratch) + HD_PARK_BYTES(H))[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HN_STAMP(k) do {} while (0)
+#endif
+
+template <int NT, bool LN>
+__global__ __launch_bounds__(OCN_BLOCK, 1) void heads_nsplit_kernel(const HeadsArgs a) {
+  using HD = Heads<NT>;
+  using HN = HeadsN<NT>;
+  using panel_t = typename HN::panel_t;
+  constexpr int H = HD::H, TW = HN::TW, PD = HN::PD, ROWS = HN::ROWS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // vectors | operand buffer | crossings
+  float* s_vec = reinterpret_cast<float*>(smem);
+  const float* s_scal = s_vec + HD_NVEC * H;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  h16x8* ob = reinterpret_cast<h16x8*>(smem + HD::LDS_W) + lane;
+  float* red = reinterpret_cast<float*>(smem + HD::LDS_W + (size_t)HN::OB_VECS * 16);
+  for (int q = threadIdx.x; q < HD::VEC_FLOATS; q += OCN_BLOCK) s_vec[q] = a.vec[q];
+  i64 m3 = a.B, m32 = a.B, m321 = a.B;
+  if (a.ranges) { m3 = a.ranges[2 * 1 + 1]; m32 = a.ranges[2 * 0 + 1]; m321 = a.ranges[2 * 3 + 1]; }
+  const i64 tile = blockIdx.x;
+  const i64 lo = tile * ROWS, hi = lo + ROWS < a.B ? lo + ROWS : a.B;
+  const i64 slot = lo + r;
+  const bool live = slot < a.B;
+  const bool wgA = lo < m32;
+  const bool wgB = a.b_on_union ? lo < m321 : (lo < m3 || (lo > m32 ? lo : m32) < (hi < m321 ? hi : m321));
+  auto row_has = [&](int br) -> bool {
+    if (!live) return false;
+    if (br == 0) return slot < m32;
+    if (br == 1) return a.b_on_union ? slot < m321 : (slot < m3 || (slot >= m32 && slot < m321));
+    return true;
+  };
+  auto panel = [&](int P) -> const char* { return a.panel[P]; };
+  const unsigned vo = (unsigned)(w * TW * 2048 + lane * 16);
+  typename HN::Acc acc;
+  typename HN::Frag fr;
+  typename HN::Own xin[3];            // this wave's quarter of the three input rows of its lane's candidate
+  const int br0 = wgA ? 0 : (wgB ? 1 : 2);
+  {                                   // all inputs and the first fragments of the first panel are requested at once
+#pragma unroll
+    for (int br = 0; br < 3; ++br) {
+      if (!(br == 0 ? wgA : (br == 1 ? wgB : true))) continue;
+      const float* xr = a.x[br] + (live ? slot : a.B - 1) * a.ldx + 4 * hh + 32 * (w * TW);
+#pragma unroll
+      for (int u = 0; u < TW; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xin[br][u][g] = *reinterpret_cast<const f32x4*>(xr + 32 * u + 8 * g);
+    }
+    const char* p0 = panel(br0 == 2 ? P_X0 : 3 * br0);
+    hd_unroll<PD>([&](auto kc) { HN::template fetch<decltype(kc)::value>(fr, vo, p0); });
+  }
+  auto zero_unless = [&](typename HN::Own& y, bool has) {
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) y[u][g] = has ? y[u][g] : (f32x4)(0.f);
+  };
+  HN_STAMP(0);
+  __syncthreads();                    // s_vec is written
+  HN_STAMP(1);
+  // (a + b): the pooled branches' shares of the last layer's input on this wave's tiles; -0 + x == x for every x
+  f32x4 sab[TW][4];
+#pragma unroll
+  for (int u = 0; u < TW; ++u)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) sab[u][g] = (f32x4)(-0.f);
+  typedef const __attribute__((address_space(1))) f32x4* gf4_t;
+  const gf4_t ck = (gf4_t)reinterpret_cast<const f32x4*>(a.cpark);
+  typename HN::Own y;
+  float inv;
+#pragma unroll
+  for (int br = 0; br < 2; ++br) {
+    if (!(br == 0 ? wgA : wgB)) {     // nobody here has this branch's input: its constant (the park layout: [4 t + g][lane])
+#pragma unroll
+      for (int u = 0; u < TW; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sab[u][g] += ck[(size_t)(br * 4 * NT + 4 * (w * TW + u) + g) * 64 + lane];
+      continue;
+    }
+    const float* vb = s_vec + (br == 0 ? V_B0A : V_B0B) * H;
+    const char *p0 = panel(3 * br), *p1 = panel(3 * br + 1), *p2 = panel(3 * br + 2);
+    const int nbr = (br == 0 && wgB) ? 1 : 2;
+    const char* pn = panel(nbr == 2 ? P_X0 : 3 * nbr);
+    zero_unless(xin[br], row_has(br));
+    HN::template operand<true>(ob, xin[br], s_scal[1 + 3 * br], inv, red, w, lane);
+    HN_STAMP(2 + 8 * br);
+    HN::template layer<false>(acc, ob, fr, vo, p0, p1);
+    HN_STAMP(3 + 8 * br);
+    HN::template bias<true>(y, acc, inv, vb, w, hh);
+    HN::template operand<false>(ob, y, s_scal[2 + 3 * br], inv, red, w, lane);
+    HN_STAMP(4 + 8 * br);
+    HN::template layer<false>(acc, ob, fr, vo, p1, p2);
+    HN_STAMP(5 + 8 * br);
+    HN::template bias<!LN>(y, acc, inv, vb + H, w, hh);
+    if constexpr (LN) HN::ln_relu(y, vb + 2 * H, vb + 3 * H, a.eps, red, w, hh, lane);
+    HN_STAMP(6 + 8 * br);
+    HN::template operand<false>(ob, y, s_scal[3 + 3 * br], inv, red, w, lane);
+    HN_STAMP(7 + 8 * br);
+    HN::template layer<false>(acc, ob, fr, vo, p2, pn);
+    HN_STAMP(8 + 8 * br);
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) sab[u][g] += HD_GRP(acc[u], g) * (f32x4)(inv);
+    HN_STAMP(9 + 8 * br);
+  }
+  // ---- xijlin, then ((share a + share b) + share c) + folded bias on this wave's tiles --------------------------------
+  const char *px = panel(P_X0), *pc = panel(P_MC);
+  zero_unless(xin[2], live);
+  HN::template operand<true>(ob, xin[2], s_scal[1 + P_X0], inv, red, w, lane);
+  HN_STAMP(18);
+  HN::template layer<false>(acc, ob, fr, vo, px, pc);
+  HN_STAMP(19);
+  HN::template bias<!LN>(y, acc, inv, s_vec + V_B0X * H, w, hh);
+  if constexpr (LN) HN::ln_relu(y, s_vec + V_GX * H, s_vec + V_EX * H, a.eps, red, w, hh, lane);
+  HN_STAMP(20);
+  HN::template operand<false>(ob, y, s_scal[1 + P_MC], inv, red, w, lane);
+  HN_STAMP(21);
+  HN::template layer<true>(acc, ob, fr, vo, pc, pc);
+  HN_STAMP(22);
+#pragma unroll
+  for (int u = 0; u < TW; ++u)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      y[u][g] = (sab[u][g] + HD_GRP(acc[u], g) * (f32x4)(inv)) + hd_lds4(s_vec + V_BF * H + 32 * (w * TW + u) + 8 * g + 4 * hh);
+  // ---- lin: LayerNorm, ReLU, Linear(H, 1) -----------------------------------------------------------------------------
+  const float* dw = s_vec + V_DOTW * H;
+  f32x4 d4 = (f32x4)(0.f);
+  if constexpr (LN) {
+    f32x4 s4 = (f32x4)(0.f);
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) s4 += y[u][g];
+    HN::cross_put(red, HN::quarter(s4), w, lane);
+    __syncthreads();
+    const float nmean = -(HN::cross_sum(red, lane) * (1.0f / (float)H));
+    f32x4 q4 = (f32x4)(0.f);
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 dd = y[u][g] + (f32x4)(nmean);
+        q4 = __builtin_elementwise_fma(dd, dd, q4);
+      }
+    HN::cross_put(red + 256, HN::quarter(q4), w, lane);
+    __syncthreads();
+    const float rstd = rsqrtf(HN::cross_sum(red + 256, lane) * (1.0f / (float)H) + a.eps);
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fo = 32 * (w * TW + u) + 8 * g + 4 * hh;
+        f32x4 z = __builtin_elementwise_fma((y[u][g] + (f32x4)(nmean)) * (f32x4)(rstd), hd_lds4(s_vec + V_GL * H + fo), hd_lds4(s_vec + V_EL * H + fo));
+        z = __builtin_elementwise_max(z, (f32x4)(0.f));
+        d4 = __builtin_elementwise_fma(z, hd_lds4(dw + fo), d4);
+      }
+  } else {
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        d4 = __builtin_elementwise_fma(__builtin_elementwise_max(y[u][g], (f32x4)(0.f)), hd_lds4(dw + 32 * (w * TW + u) + 8 * g + 4 * hh), d4);
+  }
+  HN::cross_put(red + 512, HN::quarter(d4), w, lane);
+  __syncthreads();
+  if (w == 0 && live && hh == 0) a.y[a.y_row_map ? a.y_row_map[slot] : slot] = HN::cross_sum(red + 512, lane) + s_scal[0];
+  HN_STAMP(23);
 }
 
 // Wp[s][t][hi, lo][lane][8 halves]: k-step s = 2 tt + ss consumes accumulator tile tt, registers 8 ss .. 8 ss + 7, of
@@ -688,7 +1046,33 @@ static int heads_launch(const HeadsArgs& a, i64 tiles, hipStream_t st) {
   return launch_status();
 }
 
+template <int NT, bool LN>
+static int heads_nsplit_launch(const HeadsArgs& a, hipStream_t st) {
+  static bool raised_dev[64] = {};
+  int devid = 0;
+  if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return OCN_EINVAL;
+  if (!raised_dev[devid]) {
+    const hipError_t e = hipFuncSetAttribute((const void*)heads_nsplit_kernel<NT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)HeadsN<NT>::LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    raised_dev[devid] = true;
+  }
+  const i64 tiles = (a.B + HeadsN<NT>::ROWS - 1) / HeadsN<NT>::ROWS;
+  hipLaunchKernelGGL((heads_nsplit_kernel<NT, LN>), dim3((unsigned)tiles), dim3(OCN_BLOCK), HeadsN<NT>::LDS_BYTES, st, a);
+  return launch_status();
+}
+
+// batches up to this many candidates take heads_nsplit_kernel (two rounds of 32-candidate workgroups on the 256 CUs: 74 against
+// 87 us with every branch on every row, 46 against 79 us with a Cora-like class mix; tools/headslat.py)
+static int64_t g_heads_small_batch = 16384;
+
 extern "C" {
+
+int64_t ocn_heads_small_batch(int64_t max_rows) {
+  const int64_t prev = g_heads_small_batch;
+  if (max_rows >= 0) g_heads_small_batch = max_rows;
+  return prev;
+}
 
 int64_t ocn_heads_panel_bytes(int32_t N, int32_t K) {
   if (N <= 0 || K <= 0 || (N & 31) || (K & 31)) return 0;
@@ -728,6 +1112,11 @@ int ocn_heads_fused(const OcnHeadsArgs* h, void* stream) {
   a.y = h->y; a.dump = h->dump; a.cpark = h->cpark; a.scratch = h->scratch; a.eps = h->eps; a.ln = h->ln; a.b_on_union = h->b_on_union;
   const i64 tiles = h->dump ? 1 : (h->B + HD_ROWS - 1) / HD_ROWS;
   hipStream_t st = (hipStream_t)stream;
+  if (!h->dump && h->B <= g_heads_small_batch) switch (h->H) {
+      case 128: return h->ln ? heads_nsplit_launch<4, true>(a, st) : heads_nsplit_launch<4, false>(a, st);
+      case 256: return h->ln ? heads_nsplit_launch<8, true>(a, st) : heads_nsplit_launch<8, false>(a, st);
+      default: return OCN_EINVAL;
+    }
   switch (h->H) {
     case 128: return h->ln ? heads_launch<4, true>(a, tiles, st) : heads_launch<4, false>(a, tiles, st);
     case 256: return h->ln ? heads_launch<8, true>(a, tiles, st) : heads_launch<8, false>(a, tiles, st);

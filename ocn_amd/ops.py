@@ -904,6 +904,12 @@ fused_heads_min_width = 128      # narrower heads (ppa / citation2 / ddi: H = 32
                                  # kernel's per-tile epilogues dominate and the grouped launches are faster (ddi: 18 vs 31 us)
 
 
+def heads_small_batch(max_rows: int = -1) -> int:
+    """ocn_hip.h: ocn_heads_small_batch — batches up to ``max_rows`` candidates take the latency form of the fused head (same
+    bits); returns the previous bound, a negative argument only queries."""
+    return int(_lib.lib().ocn_heads_small_batch(int(max_rows)))
+
+
 @_on_device
 def heads_fused(x1: Tensor, x2: Tensor, xij: Tensor, pack: dict, ranges: Optional[Tensor], y_row_map: Optional[Tensor],
                 b_on_union: bool, scratch: Tensor, dump: Optional[Tensor] = None) -> Optional[Tensor]:

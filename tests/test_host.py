@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(hiplib):
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
     for n in names:
         assert getattr(hiplib, n) is not None
-    assert hiplib.ocn_abi_version() == _lib.ABI_VERSION == 8
+    assert hiplib.ocn_abi_version() == _lib.ABI_VERSION == 9
     assert hiplib.ocn_scan_workspace_bytes(65536) >= 8 * (65536 // 2048 + 2)
     assert hiplib.ocn_spgemm_max_cols() >= 1_000_000
 

@@ -1514,6 +1514,48 @@ def test_fused_heads_every_width(hiplib, H, ln, monkeypatch):
     assert close(grouped, modules), (grouped - modules).abs().max()
 
 
+@pytest.mark.parametrize("H", [128, 256])
+@pytest.mark.parametrize("ln", [True, False])
+@pytest.mark.parametrize("on_union", [True, False])
+def test_heads_small_batch_kernel_is_bit_equal(hiplib, H, ln, on_union):
+    """ocn_heads_fused has two forms (heads.hip): 128 candidates per workgroup with a candidate's eight layers on one wave,
+    and — up to ``ops.heads_small_batch()`` candidates — 32 per workgroup with every layer's output features split over the
+    four waves.  Same panels, same k order, same sums: the scores must be the same BITS, whatever the batch size, with every
+    class boundary inside a tile, with rows of mixed magnitude and all-zero rows, and with a destination row map."""
+    from ocn_amd import ops
+    from ocn_amd.model import predictor_dict
+    torch.manual_seed(31 + H)
+    pred = partial(predictor_dict["cn5"], cndeg=-1)(H, H, 1, 3, 0.0, 0.0, ln).to(DEV).eval()
+    with torch.no_grad():
+        for p in pred.parameters():
+            p.mul_(1.0 + 0.5 * torch.rand_like(p))
+    pack = pred._fused_pack(H, DEV)
+    scratch = ops.buf(pred._ws, "heads_scratch", int(ops._lib.lib().ocn_heads_scratch_bytes(H)) // 4, torch.float32, DEV)
+    prev = ops.heads_small_batch()
+    try:
+        for B, (n3, n2, n1) in ((1, (1, 0, 0)), (31, (5, 9, 3)), (32, (0, 0, 0)), (33, (33, 0, 0)), (257, (100, 0, 57)),
+                                (1152, (300, 211, 97)), (4099, (1, 70, 2000)), (9000, (4000, 33, 31))):
+            x1, x2, xij = (torch.randn(B, H, device=DEV) for _ in range(3))
+            x1[::3] *= 1e-3
+            x2[:, ::5] *= 1e3
+            x1[B // 2].zero_()
+            xij[B // 3].zero_()
+            r = torch.tensor([[0, n3 + n2], [0, n3], [n3 + n2, n3 + n2 + n1], [0, n3 + n2 + n1], [n3 + n2 + n1, B], [n3, n3 + n2], [0, B]],
+                             dtype=torch.int64, device=DEV)
+            rowmap = torch.randperm(B, device=DEV)
+            for ranges, rm in ((None, None), (r, None), (r, rowmap)):
+                ys = []
+                for bound in (0, 1 << 40):
+                    ops.heads_small_batch(bound)
+                    with torch.no_grad():
+                        ys.append(ops.heads_fused(x1, x2, xij, pack, ranges, rm, on_union, scratch))
+                torch.cuda.synchronize()
+                assert torch.isfinite(ys[0]).all()
+                assert torch.equal(ys[0], ys[1]), (B, ranges is not None, rm is not None, (ys[0] - ys[1]).abs().max().item())
+    finally:
+        ops.heads_small_batch(prev)
+
+
 @pytest.mark.parametrize("scale", [1.0, 3.0e4, 1.0e-6])
 def test_heads_product_accuracy(hiplib, scale):
     """The fused heads evaluate an f32 product as three f16 MFMAs on hi/lo splits with per-row power-of-two scaling
