@@ -607,8 +607,8 @@ def main():
         dt_tr /= n_tr
         with torch.no_grad():
             pred.innerprod.fill_(0.0)
+        graphed[0] = None                          # (step() finishes launch by launch)
         step(0)
-        graphed[0] = None
 
     if rank == 0:
         per = [batch_bytes(wl, m, H) for m in mines]

@@ -505,10 +505,6 @@ int ocn_heads_fused(const OcnHeadsArgs* args, void* stream);
  * its latency (Cora's 1 152-candidate batch: nine 128-row tiles = 70 us whatever the batch size).  Sets the bound (process-wide;
  * default 16384 = two rounds of workgroups on 256 CUs) and returns the previous one; a negative argument only queries. */
 int64_t ocn_heads_small_batch(int64_t max_rows);
-/* The form larger batches take: 0 = 128 candidates per workgroup, a candidate's layers on one wave (one wave per SIMD);
- * 2 = the output-split form with 64 candidates per workgroup (two workgroups per CU).  Same bits.  Returns the previous form;
- * any other argument only queries. */
-int32_t ocn_heads_form(int32_t form);
 
 /* Training-side pieces (NeighborOverlap_large.py:56-63, 76-90).
  *

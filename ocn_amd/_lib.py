@@ -96,7 +96,6 @@ SIGNATURES = {
     "ocn_heads_split_weight": (c_int32, [_P, c_int32, c_int32, c_float, _P, _P]),
     "ocn_heads_fused": (c_int32, [_P, _P]),
     "ocn_heads_small_batch": (c_int64, [c_int64]),
-    "ocn_heads_form": (c_int32, [c_int32]),
 }
 
 

@@ -670,60 +670,41 @@ __global__ __launch_bounds__(OCN_BLOCK, 1) void heads_fused_kernel(const HeadsAr
 #endif
 }
 
-// ---- the output-split form: G x 32 candidates per workgroup, the four waves split every layer's OUTPUT features ------------
+// ---- small batches: the same head on a tile of 32 candidates per workgroup (latency instead of throughput) -------------
 // heads_fused_kernel walks a candidate through eight layers on ONE wave: 8 x (12 288 matrix-pipe cycles + epilogue) = 70 us
-// whatever the batch size — Cora's whole 1 152-candidate batch is nine such tiles on nine CUs — and its 460 registers leave a
-// SIMD one wave, so nothing runs under an epilogue.  Here wave w owns accumulator tiles w NT/4 ... of every layer for all the
-// workgroup's candidates: a quarter of the k-loop's MFMAs and a quarter of every epilogue.  What the next layer needs of a
-// finished one is its B operand: a lane's eight f16 pairs of k-step (t, ss) are the split of the SAME lane's accumulator
-// registers 8 ss .. 8 ss + 7 of tile t, so the wave that owns tile t splits its results once and stores both fragments where
-// all four waves read them — the operand buffer [group][k-step][hi, lo][lane], 2 NT KiB of LDS per 32 candidates; no wave holds
-// a whole activation row.  Row maxima (the scale) and the LayerNorm sums cross the waves through small LDS arrays.  A weight
-// fragment is used by exactly one wave of the workgroup: L2 -> registers, PD k-steps ahead (no LDS ring, no LDS-DMA).
-//   G = 1 (32 candidates, one workgroup per CU): the latency form — a batch of up to ocn_heads_small_batch() candidates.
-//   G = 2 (64 candidates, <= 256 registers, the epilogue vectors read from L2 instead of LDS): two workgroups per CU, one's
-//   epilogues under the other's MFMAs.
+// whatever the batch size — Cora's whole 1 152-candidate batch is nine such tiles on nine CUs.  Here the four waves of a
+// workgroup share 32 candidates and split the OUTPUT features of every layer: wave w owns accumulator tiles w NT/4 ...,
+// a quarter of the k-loop's MFMAs, and a quarter of every epilogue.  What the next layer needs of a finished one is its B
+// operand: a lane's eight f16 pairs of k-step (t, ss) are the split of the SAME lane's accumulator registers 8 ss .. 8 ss + 7 of
+// tile t, so the wave that owns tile t splits its results once and stores both fragments where all four waves read them —
+// the operand buffer [k-step][hi, lo][lane], 2 NT KiB of LDS; no wave holds a whole activation row.  Row maxima (the scale)
+// and the LayerNorm sums cross the waves through three small LDS arrays.  A weight fragment is used by exactly one wave of
+// the workgroup: L2 -> registers, PD k-steps ahead (no LDS ring, no LDS-DMA).
 // The arithmetic is heads_fused_kernel's, operation for operation — same panels, same k order, same split, same row scales,
-// the sums over a row's features as four quarter sums combined (P0 + P1) + (P2 + P3) in both kernels (hd_quad) — so all forms
+// the sums over a row's features as four quarter sums combined (P0 + P1) + (P2 + P3) in both kernels (hd_quad) — so the two
 // return the same BITS (tests/test_parity_gpu.py::test_heads_small_batch_kernel_is_bit_equal); a tile none of whose
 // candidates has a branch's input takes the branch's constant from cpark, as there.
-template <int NT, int G>
+template <int NT>
 struct HeadsN {
   using HD = Heads<NT>;
-  static constexpr int H = 32 * NT, KS = HD::KS, TW = NT / 4, PD = (G == 1 ? 8 : 2), ROWS = 32 * G;
-  static constexpr int MAX_GRID = 2 * HD_MAX_GRID;                            // G = 2: persistent, two workgroups per CU
-  static constexpr size_t PARK_VECS = (size_t)2 * G * TW * 4 * OCN_BLOCK;       // G = 2: a workgroup's parked shares, in f32x4
-  static constexpr bool VEC_LDS = G == 1;                                       // the epilogue vectors: LDS, or straight from a.vec
-  static constexpr int OB_VECS = G * KS * 2 * 64;                               // the operand buffer, in 16-byte fragments per lane
-  static constexpr int RED_FLOATS = G * 3 * 4 * 64;                             // [group][sums | squares / dot | maxima][wave][lane]
-  static constexpr size_t LDS_VEC = VEC_LDS ? (size_t)HD::LDS_W : 0;
-  static constexpr size_t LDS_BYTES = LDS_VEC + (size_t)OB_VECS * 16 + (size_t)RED_FLOATS * 4;
+  static constexpr int H = 32 * NT, KS = HD::KS, TW = NT / 4, PD = 8, ROWS = 32;
+  static constexpr int OB_VECS = KS * 2 * 64;                                   // the operand buffer, in 16-byte fragments per lane
+  static constexpr int RED_FLOATS = 3 * 4 * 64;                                 // sums, squares / dot, maxima: [wave][lane]
+  static constexpr size_t LDS_BYTES = (size_t)HD::LDS_W + (size_t)OB_VECS * 16 + (size_t)RED_FLOATS * 4;
   typedef h16x8 Frag[PD][TW][2];
-  typedef f32x16 Acc[G][TW];
-  typedef f32x4 Own[G][TW][4];         // this wave's part of a layer's output: [group][u][g][j] = feature 32 (w TW + u) + 8 g + 4 hh + j
+  typedef f32x16 Acc[TW];
+  typedef f32x4 Own[TW][4];            // this wave's part of a layer's output: [u][g][j] = feature 32 (w TW + u) + 8 g + 4 hh + j
+  typedef const __attribute__((address_space(1))) h16x8* panel_t;
   static_assert(PD <= KS && KS % PD == 0, "prefetch ring");
-
-  // 16 bytes of an epilogue vector (LDS: inferred from s_vec; global: a.vec, every lane of a half-wave the same address)
-  // (p uniform, h4 = 4 hh the lane's part: a scalar base and one 32-bit lane offset for every vector, not an address pair each)
-  static __device__ __forceinline__ f32x4 vld(const float* p, unsigned h4) {
-    if constexpr (VEC_LDS) return *reinterpret_cast<const f32x4*>(p + h4);
-    else return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((const __attribute__((address_space(1))) float*)p + h4);
-  }
 
   // The fragments (hi, lo) of k-step s for this wave's tiles: panel + vo + s NT 2 KiB, vo = (w TW 2) KiB + 16 lane.  Requested by
   // hand and waited for by count (wait<>): left to the compiler, the requests of a prefetch ring this deep sink down to their
   // uses — one L2 round trip per k-step.  Vector-memory operations complete in order, so "at most N outstanding" means the
   // N youngest; requests the compiler makes itself only make a count stricter than needed.
-  // (G = 2 lives at the register limit, where the allocator may move or spill a register the hardware has not written yet —
-  // it cannot know: there the requests are ordinary loads, two k-steps ahead, and the other workgroup's waves hide the rest)
-  static constexpr bool ASM_LOADS = G == 1;
   template <int IMM>
   static __device__ __forceinline__ void gload(h16x8& f, unsigned vo, const char* panel) {
     static_assert(IMM >= 0 && IMM < 4096, "global offset");
-    if constexpr (ASM_LOADS)
-      asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(f) : "v"(vo), "s"(panel), "i"(IMM));    // (read-only data: no memory clobber, LDS reads may pass)
-    else
-      f = *reinterpret_cast<const __attribute__((address_space(1))) h16x8*>((const __attribute__((address_space(1))) char*)panel + vo + IMM);
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(f) : "v"(vo), "s"(panel), "i"(IMM));      // (read-only data: no memory clobber, LDS reads may pass)
   }
   template <int S>
   static __device__ __forceinline__ void fetch(Frag& f, unsigned vo, const char* panel) {
@@ -736,51 +717,48 @@ struct HeadsN {
   }
   template <int N, int K>
   static __device__ __forceinline__ void wait(Frag& f) {
-    if constexpr (!ASM_LOADS) return;
-    else if constexpr (TW == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(f[K][0][0]), "+v"(f[K][0][1]), "+v"(f[K][1][0]), "+v"(f[K][1][1]) : "i"(N));
+    if constexpr (TW == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(f[K][0][0]), "+v"(f[K][0][1]), "+v"(f[K][1][0]), "+v"(f[K][1][1]) : "i"(N));
     else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f[K][0][0]), "+v"(f[K][0][1]) : "i"(N));
   }
-  static __device__ __forceinline__ void pin(Acc& acc) {
+
+  // Every request has landed.  Wherever control flow joins (a skipped branch), the two paths may hold the ring in different
+  // registers and the compiler reconciles them with moves — of registers it believes written: no request may be in flight there
+  // (tools/check_heads_asm.py, rule 1, found exactly such a move).
+  static __device__ __forceinline__ void drain(Frag& f) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi)
+    for (int k = 0; k < PD; ++k)
 #pragma unroll
-      for (int u = 0; u < TW; ++u) asm volatile("" : "+a"(acc[gi][u]));
+      for (int u = 0; u < TW; ++u) asm volatile("" : "+v"(f[k][u][0]), "+v"(f[k][u][1]));
   }
 
   // acc = (this wave's rows of Wp) . (the operand buffer); the fragments of the first PD k-steps are on their way, the layer
   // leaves those of the next panel so
   template <bool LAST>
   static __device__ __forceinline__ void layer(Acc& acc, const h16x8* ob /* + lane */, Frag& f, unsigned vo, const char* p_cur, const char* p_nxt) {
-    h16x8 bq[2][G][2];                                                                  // the B operands, one k-step ahead
-#pragma unroll
-    for (int gi = 0; gi < G; ++gi) { bq[0][gi][0] = ob[(gi * KS * 2) * 64]; bq[0][gi][1] = ob[(gi * KS * 2 + 1) * 64]; }
+    h16x8 bq[2][2] = {{ob[0], ob[64]}, {}};                                              // the B operand, one k-step ahead
     hd_unroll<KS>([&](auto sc_) {
       constexpr int s = decltype(sc_)::value, k = s % PD;
       constexpr int ahead = (LAST && KS - 1 - s < PD - 1) ? KS - 1 - s : PD - 1;       // k-steps requested after this one
-      if constexpr (s + 1 < KS) {
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi) {
-          bq[(s + 1) & 1][gi][0] = ob[((gi * KS + s + 1) * 2) * 64];
-          bq[(s + 1) & 1][gi][1] = ob[((gi * KS + s + 1) * 2 + 1) * 64];
-        }
-      }
+      if constexpr (s + 1 < KS) { bq[(s + 1) & 1][0] = ob[(2 * s + 2) * 64]; bq[(s + 1) & 1][1] = ob[(2 * s + 3) * 64]; }
+      const h16x8 bh = bq[s & 1][0], bl = bq[s & 1][1];
       wait<ahead * 2 * TW, k>(f);
 #pragma unroll
-      for (int u = 0; u < TW; ++u)
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi) {
-          const h16x8 bh = bq[s & 1][gi][0], bl = bq[s & 1][gi][1];
-          if constexpr (s == 0) acc[gi][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k][u][0], bl, (f32x16)(0.f), 0, 0, 0);     // wh . xl
-          else acc[gi][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k][u][0], bl, acc[gi][u], 0, 0, 0);
-          acc[gi][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k][u][1], bh, acc[gi][u], 0, 0, 0);                                // wl . xh
-          acc[gi][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k][u][0], bh, acc[gi][u], 0, 0, 0);                                // wh . xh
-        }
+      for (int u = 0; u < TW; ++u) {
+        if constexpr (s == 0) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k][u][0], bl, (f32x16)(0.f), 0, 0, 0);     // wh . xl
+        else acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k][u][0], bl, acc[u], 0, 0, 0);
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k][u][1], bh, acc[u], 0, 0, 0);                                  // wl . xh
+        acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[k][u][0], bh, acc[u], 0, 0, 0);                                  // wh . xh
+      }
       // the ring slot is free once its MFMAs have read it: the request is issued behind them in program order, and a load's
       // write-back cannot pass an earlier instruction's operand read
       if constexpr (s + PD < KS) { pin(acc); fetch<s + PD>(f, vo, p_cur); }
-      else if constexpr (!LAST) { pin(acc); fetch<s + PD - KS>(f, vo, p_nxt); }
-      if constexpr (!ASM_LOADS) __builtin_amdgcn_sched_barrier(0);      // (the scheduler may not sink the requests to their uses)
+      else if constexpr (!LAST) { pin(acc); fetch<s + PD - KS + 0>(f, vo, p_nxt); }
     });
+  }
+  static __device__ __forceinline__ void pin(Acc& acc) {
+#pragma unroll
+    for (int u = 0; u < TW; ++u) asm volatile("" : "+a"(acc[u]));
   }
 
   // (R0 + R1) + (R2 + R3) of the four waves' values of this lane: `mine` goes to red[w][lane], everybody reads all four
@@ -791,65 +769,50 @@ struct HeadsN {
   static __device__ __forceinline__ float cross_max(const float* red, int lane) {
     return fmaxf(fmaxf(red[lane], red[64 + lane]), fmaxf(red[128 + lane], red[192 + lane]));
   }
-  static __device__ __forceinline__ float* red_of(float* red, int gi, int which) { return red + (gi * 3 + which) * 256; }
+  static __device__ __forceinline__ float quarter(const f32x4& p) { return hd_quarter(p); }      // this wave's P_w of hd_quad
 
   // y = acc * inv + v[feature] (ReLU) on this wave's tiles
   template <bool RELU>
-  static __device__ __forceinline__ void bias(Own& y, Acc& acc, const float (&inv)[G], const float* v, int w, int hh) {
+  static __device__ __forceinline__ void bias(Own& y, Acc& acc, float inv, const float* v, int w, int hh) {
 #pragma unroll
     for (int u = 0; u < TW; ++u)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 b = vld(v + 32 * (w * TW + u) + 8 * g, 4u * hh);
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi) {
-          y[gi][u][g] = __builtin_elementwise_fma(HD_GRP(acc[gi][u], g), (f32x4)(inv[gi]), b);
-          if constexpr (RELU) y[gi][u][g] = __builtin_elementwise_max(y[gi][u][g], (f32x4)(0.f));
-        }
+        y[u][g] = __builtin_elementwise_fma(HD_GRP(acc[u], g), (f32x4)(inv), hd_lds4(v + 32 * (w * TW + u) + 8 * g + 4 * hh));
+        if constexpr (RELU) y[u][g] = __builtin_elementwise_max(y[u][g], (f32x4)(0.f));
       }
   }
   // y = ReLU(LayerNorm(y)) over the whole row (two crossings); Heads::bias_ln_relu's arithmetic
   static __device__ __forceinline__ void ln_relu(Own& y, const float* gm, const float* bt, float eps, float* red, int w, int hh, int lane) {
+    f32x4 s4 = (f32x4)(0.f);
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi) {
-      f32x4 s4 = (f32x4)(0.f);
+    for (int u = 0; u < TW; ++u)
 #pragma unroll
-      for (int u = 0; u < TW; ++u)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) s4 += y[gi][u][g];
-      cross_put(red_of(red, gi, 0), hd_quarter(s4), w, lane);
-    }
+      for (int g = 0; g < 4; ++g) s4 += y[u][g];
+    cross_put(red, quarter(s4), w, lane);
     __syncthreads();
-#pragma unroll
-    for (int gi = 0; gi < G; ++gi) {
-      const float nmean = -(cross_sum(red_of(red, gi, 0), lane) * (1.0f / (float)H));
-      f32x4 q4 = (f32x4)(0.f);
-#pragma unroll
-      for (int u = 0; u < TW; ++u)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 d = y[gi][u][g] + (f32x4)(nmean);
-          q4 = __builtin_elementwise_fma(d, d, q4);
-          y[gi][u][g] = d;
-        }
-      cross_put(red_of(red, gi, 1), hd_quarter(q4), w, lane);
-    }
-    __syncthreads();
-    float rstd[G];
-#pragma unroll
-    for (int gi = 0; gi < G; ++gi) rstd[gi] = rsqrtf(cross_sum(red_of(red, gi, 1), lane) * (1.0f / (float)H) + eps);
+    const float nmean = -(cross_sum(red, lane) * (1.0f / (float)H));
+    f32x4 q4 = (f32x4)(0.f);
 #pragma unroll
     for (int u = 0; u < TW; ++u)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int fo = 32 * (w * TW + u) + 8 * g;
-        const f32x4 gg = vld(gm + fo, 4u * hh), bb = vld(bt + fo, 4u * hh);
+        const f32x4 d = y[u][g] + (f32x4)(nmean);
+        q4 = __builtin_elementwise_fma(d, d, q4);
+        y[u][g] = d;
+      }
+    cross_put(red + 256, quarter(q4), w, lane);
+    __syncthreads();
+    const float rstd = rsqrtf(cross_sum(red + 256, lane) * (1.0f / (float)H) + eps);
 #pragma unroll
-        for (int gi = 0; gi < G; ++gi)
-          y[gi][u][g] = __builtin_elementwise_max(__builtin_elementwise_fma(y[gi][u][g] * (f32x4)(rstd[gi]), gg, bb), (f32x4)(0.f));
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fo = 32 * (w * TW + u) + 8 * g + 4 * hh;
+        y[u][g] = __builtin_elementwise_max(__builtin_elementwise_fma(y[u][g] * (f32x4)(rstd), hd_lds4(gm + fo), hd_lds4(bt + fo)), (f32x4)(0.f));
       }
   }
-  // hd_split's arithmetic as plain expressions (the splits of an operand step are independent chains the scheduler may
+  // hd_split's arithmetic as plain expressions (the sixteen splits of an operand step are independent chains the scheduler may
   // interleave; the asm form is one block each): H = f16x2(x sc), L = f16x2(x sc - f32(H)), every step correctly rounded
   static __device__ __forceinline__ void split(float x0, float x1, float sc, unsigned& Hh, unsigned& Ll) {
     typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
@@ -863,33 +826,27 @@ struct HeadsN {
   // ABS: raw inputs (any sign) instead of ReLU outputs.  The closing barrier also ends the previous k-loop's reads of `ob`:
   // every wave is past it before the first store below (the crossing's barrier stands between).
   template <bool ABS>
-  static __device__ __forceinline__ void operand(h16x8* ob /* + lane */, Own& y, float pinv, float (&inv)[G], float* red, int w, int lane) {
+  static __device__ __forceinline__ void operand(h16x8* ob /* + lane */, Own& y, float pinv, float& inv, float* red, int w, int lane) {
+    float m = 0.f;
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi) {
-      float m = 0.f;
+    for (int u = 0; u < TW; ++u)
 #pragma unroll
-      for (int u = 0; u < TW; ++u)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) m = hd_max4(m, ABS ? __builtin_elementwise_abs(y[gi][u][g]) : y[gi][u][g]);
-      cross_put(red_of(red, gi, 2), m, w, lane);
-    }
+      for (int g = 0; g < 4; ++g) m = hd_max4(m, ABS ? __builtin_elementwise_abs(y[u][g]) : y[u][g]);
+    cross_put(red + 512, m, w, lane);
     __syncthreads();
+    float sc;
+    hd_row_scale(cross_max(red + 512, lane), pinv, sc, inv);
 #pragma unroll
-    for (int gi = 0; gi < G; ++gi) {
-      float sc;
-      hd_row_scale(cross_max(red_of(red, gi, 2), lane), pinv, sc, inv[gi]);
+    for (int u = 0; u < TW; ++u)
 #pragma unroll
-      for (int u = 0; u < TW; ++u)
+      for (int ss = 0; ss < 2; ++ss) {
+        unsigned xh[4], xl[4];
 #pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-          unsigned xh[4], xl[4];
-#pragma unroll
-          for (int p = 0; p < 4; ++p) split(y[gi][u][2 * ss + (p >> 1)][2 * (p & 1)], y[gi][u][2 * ss + (p >> 1)][2 * (p & 1) + 1], sc, xh[p], xl[p]);
-          const int s = 2 * (w * TW + u) + ss;
-          ob[((gi * KS + s) * 2) * 64] = hd_frag(xh);
-          ob[((gi * KS + s) * 2 + 1) * 64] = hd_frag(xl);
-        }
-    }
+        for (int p = 0; p < 4; ++p) split(y[u][2 * ss + (p >> 1)][2 * (p & 1)], y[u][2 * ss + (p >> 1)][2 * (p & 1) + 1], sc, xh[p], xl[p]);
+        const int s = 2 * (w * TW + u) + ss;
+        ob[(2 * s) * 64] = hd_frag(xh);
+        ob[(2 * s + 1) * 64] = hd_frag(xl);
+      }
     __syncthreads();
   }
 };
@@ -901,254 +858,173 @@ struct HeadsN {
 #define HN_STAMP(k) do {} while (0)
 #endif
 
-template <int NT, bool LN, int G>
-__global__ __launch_bounds__(OCN_BLOCK, G) void heads_nsplit_kernel(const HeadsArgs a) {
+template <int NT, bool LN>
+__global__ __launch_bounds__(OCN_BLOCK, 1) void heads_nsplit_kernel(const HeadsArgs a) {
   using HD = Heads<NT>;
-  using HN = HeadsN<NT, G>;
+  using HN = HeadsN<NT>;
+  using panel_t = typename HN::panel_t;
   constexpr int H = HD::H, TW = HN::TW, PD = HN::PD, ROWS = HN::ROWS;
-  constexpr bool PARK = G > 1;        // the pooled branches' shares wait in the workgroup's park area (L2) instead of registers
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // (vectors) | operand buffer | crossings
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];     // vectors | operand buffer | crossings
+  float* s_vec = reinterpret_cast<float*>(smem);
+  const float* s_scal = s_vec + HD_NVEC * H;
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int r = lane & 31, hh = lane >> 5;
-  h16x8* ob = reinterpret_cast<h16x8*>(smem + HN::LDS_VEC) + lane;
-  float* red = reinterpret_cast<float*>(smem + HN::LDS_VEC + (size_t)HN::OB_VECS * 16);
-  const float* vec_ = a.vec;          // the epilogue vectors: LDS (G = 1) or where the caller has them
-  if constexpr (HN::VEC_LDS) {
-    float* s_vec = reinterpret_cast<float*>(smem);
-    for (int q = threadIdx.x; q < HD::VEC_FLOATS; q += OCN_BLOCK) s_vec[q] = a.vec[q];
-    vec_ = s_vec;
-    __syncthreads();
-  }
-  const float* scal = a.vec + HD_NVEC * H;            // uniform scalars: straight from the caller's copy (scalar loads)
+  h16x8* ob = reinterpret_cast<h16x8*>(smem + HD::LDS_W) + lane;
+  float* red = reinterpret_cast<float*>(smem + HD::LDS_W + (size_t)HN::OB_VECS * 16);
+  for (int q = threadIdx.x; q < HD::VEC_FLOATS; q += OCN_BLOCK) s_vec[q] = a.vec[q];
   i64 m3 = a.B, m32 = a.B, m321 = a.B;
   if (a.ranges) { m3 = a.ranges[2 * 1 + 1]; m32 = a.ranges[2 * 0 + 1]; m321 = a.ranges[2 * 3 + 1]; }
-  const i64 n_tiles = (a.B + ROWS - 1) / ROWS;
-  const unsigned vo_ = (unsigned)(w * TW * 2048 + lane * 16);
-  typedef __attribute__((address_space(1))) f32x4* gp4_t;
-  typedef const __attribute__((address_space(1))) f32x4* gf4_t;
-  const gf4_t ck_ = (gf4_t)reinterpret_cast<const f32x4*>(a.cpark) + lane;
-  const gp4_t park_ = (gp4_t)(reinterpret_cast<f32x4*>(a.scratch) + (size_t)blockIdx.x * HN::PARK_VECS) + threadIdx.x;
-  // tiles in snake order over the grid's rounds (heads_fused_kernel: class-major rows, tile cost falls with the index)
-  auto tile_at = [&](i64 q) -> i64 {
-    const i64 Gd = gridDim.x;
-    const i64 t = q * Gd + ((q & 1) ? Gd - 1 - (i64)blockIdx.x : (i64)blockIdx.x);
-    return t < n_tiles ? t : -1;
+  const i64 tile = blockIdx.x;
+  const i64 lo = tile * ROWS, hi = lo + ROWS < a.B ? lo + ROWS : a.B;
+  const i64 slot = lo + r;
+  const bool live = slot < a.B;
+  const bool wgA = lo < m32;
+  const bool wgB = a.b_on_union ? lo < m321 : (lo < m3 || (lo > m32 ? lo : m32) < (hi < m321 ? hi : m321));
+  auto row_has = [&](int br) -> bool {
+    if (!live) return false;
+    if (br == 0) return slot < m32;
+    if (br == 1) return a.b_on_union ? slot < m321 : (slot < m3 || (slot >= m32 && slot < m321));
+    return true;
   };
-#pragma unroll 1
-  for (i64 round = 0;; ++round) {
-    const i64 tile = tile_at(round);
-    if (tile < 0) break;
-    const i64 lo = tile * ROWS, hi = lo + ROWS < a.B ? lo + ROWS : a.B;
-    const bool wgA = lo < m32;
-    const bool wgB = a.b_on_union ? lo < m321 : (lo < m3 || (lo > m32 ? lo : m32) < (hi < m321 ? hi : m321));
-    // (opaque per tile: or the addresses of every park element and of every k-step's fragments are hoisted out of the tile
-    // loop — a hundred registers that then spill)
-    unsigned vo = vo_;
-    gp4_t park = park_;
-    gf4_t ck = ck_;
-    asm volatile("" : "+v"(vo), "+v"(park), "+v"(ck));
-    const float* vec = vec_;
-    if constexpr (!HN::VEC_LDS) asm volatile("" : "+s"(vec));              // (... and of every epilogue vector's sixteen-byte pieces)
-    auto slot_of = [&](int gi) -> i64 { return lo + 32 * gi + r; };
-    auto row_has = [&](int gi, int br) -> bool {
-      const i64 sl = slot_of(gi);
-      if (sl >= a.B) return false;
-      if (br == 0) return sl < m32;
-      if (br == 1) return a.b_on_union ? sl < m321 : (sl < m3 || (sl >= m32 && sl < m321));
-      return true;
-    };
-    auto panel = [&](int P) -> const char* { return a.panel[P]; };
-    typename HN::Acc acc;
-    typename HN::Frag fr;
-    typename HN::Own y;
-    // this wave's quarter of a branch's input rows (zero where a candidate has none)
-    auto x_rows = [&](int br) {
+  auto panel = [&](int P) -> const char* { return a.panel[P]; };
+  const unsigned vo = (unsigned)(w * TW * 2048 + lane * 16);
+  typename HN::Acc acc;
+  typename HN::Frag fr;
+  typename HN::Own xin[3];            // this wave's quarter of the three input rows of its lane's candidate
+  const int br0 = wgA ? 0 : (wgB ? 1 : 2);
+  {                                   // all inputs and the first fragments of the first panel are requested at once
 #pragma unroll
-      for (int gi = 0; gi < G; ++gi) {
-        const i64 sl = slot_of(gi);
-        const float* xr = a.x[br] + (sl < a.B ? sl : a.B - 1) * a.ldx + 4 * hh + 32 * (w * TW);
-        const bool has = row_has(gi, br);
+    for (int br = 0; br < 3; ++br) {
+      if (!(br == 0 ? wgA : (br == 1 ? wgB : true))) continue;
+      const float* xr = a.x[br] + (live ? slot : a.B - 1) * a.ldx + 4 * hh + 32 * (w * TW);
 #pragma unroll
-        for (int u = 0; u < TW; ++u)
+      for (int u = 0; u < TW; ++u)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 32 * u + 8 * g);
-            y[gi][u][g] = has ? v : (f32x4)(0.f);
-          }
-      }
-    };
-    const int br0 = wgA ? 0 : (wgB ? 1 : 2);
-    x_rows(br0);
-    {
-      const char* p0 = panel(br0 == 2 ? P_X0 : 3 * br0);
-      hd_unroll<PD>([&](auto kc) { HN::template fetch<decltype(kc)::value>(fr, vo, p0); });
+        for (int g = 0; g < 4; ++g) xin[br][u][g] = *reinterpret_cast<const f32x4*>(xr + 32 * u + 8 * g);
     }
-    HN_STAMP(1);
-    // (a + b): the pooled branches' shares of the last layer's input on this wave's tiles; -0 + x == x for every x
-    f32x4 sab[PARK ? 1 : G][PARK ? 1 : TW][4];
-    if constexpr (!PARK) {
+    const char* p0 = panel(br0 == 2 ? P_X0 : 3 * br0);
+    hd_unroll<PD>([&](auto kc) { HN::template fetch<decltype(kc)::value>(fr, vo, p0); });
+  }
+  auto zero_unless = [&](typename HN::Own& y, bool has) {
 #pragma unroll
-      for (int gi = 0; gi < G; ++gi)
+    for (int u = 0; u < TW; ++u)
 #pragma unroll
-        for (int u = 0; u < TW; ++u)
+      for (int g = 0; g < 4; ++g) y[u][g] = has ? y[u][g] : (f32x4)(0.f);
+  };
+  HN_STAMP(0);
+  __syncthreads();                    // s_vec is written
+  HN_STAMP(1);
+  // (a + b): the pooled branches' shares of the last layer's input on this wave's tiles; -0 + x == x for every x
+  f32x4 sab[TW][4];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) sab[gi][u][g] = (f32x4)(-0.f);
+  for (int u = 0; u < TW; ++u)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) sab[u][g] = (f32x4)(-0.f);
+  typedef const __attribute__((address_space(1))) f32x4* gf4_t;
+  const gf4_t ck = (gf4_t)reinterpret_cast<const f32x4*>(a.cpark);
+  typename HN::Own y;
+  float inv;
+  HN::drain(fr);                      // (the input rows are awaited here anyway)
+#pragma unroll
+  for (int br = 0; br < 2; ++br) {
+    if (!(br == 0 ? wgA : wgB)) {     // nobody here has this branch's input: its constant (the park layout: [4 t + g][lane])
+#pragma unroll
+      for (int u = 0; u < TW; ++u)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sab[u][g] += ck[(size_t)(br * 4 * NT + 4 * (w * TW + u) + g) * 64 + lane];
+      continue;
     }
-    float inv[G];
+    const float* vb = s_vec + (br == 0 ? V_B0A : V_B0B) * H;
+    const char *p0 = panel(3 * br), *p1 = panel(3 * br + 1), *p2 = panel(3 * br + 2);
+    const int nbr = (br == 0 && wgB) ? 1 : 2;
+    const char* pn = panel(nbr == 2 ? P_X0 : 3 * nbr);
+    zero_unless(xin[br], row_has(br));
+    HN::template operand<true>(ob, xin[br], s_scal[1 + 3 * br], inv, red, w, lane);
+    HN_STAMP(2 + 8 * br);
+    HN::template layer<false>(acc, ob, fr, vo, p0, p1);
+    HN_STAMP(3 + 8 * br);
+    HN::template bias<true>(y, acc, inv, vb, w, hh);
+    HN::template operand<false>(ob, y, s_scal[2 + 3 * br], inv, red, w, lane);
+    HN_STAMP(4 + 8 * br);
+    HN::template layer<false>(acc, ob, fr, vo, p1, p2);
+    HN_STAMP(5 + 8 * br);
+    HN::template bias<!LN>(y, acc, inv, vb + H, w, hh);
+    if constexpr (LN) HN::ln_relu(y, vb + 2 * H, vb + 3 * H, a.eps, red, w, hh, lane);
+    HN_STAMP(6 + 8 * br);
+    HN::template operand<false>(ob, y, s_scal[3 + 3 * br], inv, red, w, lane);
+    HN_STAMP(7 + 8 * br);
+    HN::template layer<false>(acc, ob, fr, vo, p2, pn);
+    HN_STAMP(8 + 8 * br);
 #pragma unroll
-    for (int br = 0; br < 2; ++br) {
-      if (!(br == 0 ? wgA : wgB)) {     // nobody here has this branch's input: its constant (the park layout: [4 t + g][lane])
-        if constexpr (!PARK) {
+    for (int u = 0; u < TW; ++u)
 #pragma unroll
-          for (int u = 0; u < TW; ++u)
+      for (int g = 0; g < 4; ++g) sab[u][g] += HD_GRP(acc[u], g) * (f32x4)(inv);
+    HN::drain(fr);                    // (the paths join below)
+    HN_STAMP(9 + 8 * br);
+  }
+  // ---- xijlin, then ((share a + share b) + share c) + folded bias on this wave's tiles --------------------------------
+  const char *px = panel(P_X0), *pc = panel(P_MC);
+  zero_unless(xin[2], live);
+  HN::template operand<true>(ob, xin[2], s_scal[1 + P_X0], inv, red, w, lane);
+  HN_STAMP(18);
+  HN::template layer<false>(acc, ob, fr, vo, px, pc);
+  HN_STAMP(19);
+  HN::template bias<!LN>(y, acc, inv, s_vec + V_B0X * H, w, hh);
+  if constexpr (LN) HN::ln_relu(y, s_vec + V_GX * H, s_vec + V_EX * H, a.eps, red, w, hh, lane);
+  HN_STAMP(20);
+  HN::template operand<false>(ob, y, s_scal[1 + P_MC], inv, red, w, lane);
+  HN_STAMP(21);
+  HN::template layer<true>(acc, ob, fr, vo, pc, pc);
+  HN_STAMP(22);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const f32x4 c = ck[(size_t)(br * 4 * NT + 4 * (w * TW + u) + g) * 64];
+  for (int u = 0; u < TW; ++u)
 #pragma unroll
-              for (int gi = 0; gi < G; ++gi) sab[gi][u][g] += c;
-            }
-        }
-        continue;
-      }
-      const float* vb = vec + (br == 0 ? V_B0A : V_B0B) * H;
-      const char *p0 = panel(3 * br), *p1 = panel(3 * br + 1), *p2 = panel(3 * br + 2);
-      const int nbr = (br == 0 && wgB) ? 1 : 2;
-      const char* pn = panel(nbr == 2 ? P_X0 : 3 * nbr);
-      if (br != br0) x_rows(br);
-      HN::template operand<true>(ob, y, scal[1 + 3 * br], inv, red, w, lane);
-      HN_STAMP(2 + 8 * br);
-      HN::template layer<false>(acc, ob, fr, vo, p0, p1);
-      HN_STAMP(3 + 8 * br);
-      HN::template bias<true>(y, acc, inv, vb, w, hh);
-      HN::template operand<false>(ob, y, scal[2 + 3 * br], inv, red, w, lane);
-      HN_STAMP(4 + 8 * br);
-      HN::template layer<false>(acc, ob, fr, vo, p1, p2);
-      HN_STAMP(5 + 8 * br);
-      HN::template bias<!LN>(y, acc, inv, vb + H, w, hh);
-      if constexpr (LN) HN::ln_relu(y, vb + 2 * H, vb + 3 * H, a.eps, red, w, hh, lane);
-      HN_STAMP(6 + 8 * br);
-      HN::template operand<false>(ob, y, scal[3 + 3 * br], inv, red, w, lane);
-      HN_STAMP(7 + 8 * br);
-      HN::template layer<false>(acc, ob, fr, vo, p2, pn);
-      HN_STAMP(8 + 8 * br);
+    for (int g = 0; g < 4; ++g)
+      y[u][g] = (sab[u][g] + HD_GRP(acc[u], g) * (f32x4)(inv)) + hd_lds4(s_vec + V_BF * H + 32 * (w * TW + u) + 8 * g + 4 * hh);
+  // ---- lin: LayerNorm, ReLU, Linear(H, 1) -----------------------------------------------------------------------------
+  const float* dw = s_vec + V_DOTW * H;
+  f32x4 d4 = (f32x4)(0.f);
+  if constexpr (LN) {
+    f32x4 s4 = (f32x4)(0.f);
 #pragma unroll
-      for (int gi = 0; gi < G; ++gi)
+    for (int u = 0; u < TW; ++u)
 #pragma unroll
-        for (int u = 0; u < TW; ++u)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 sh = HD_GRP(acc[gi][u], g) * (f32x4)(inv[gi]);
-            if constexpr (PARK) park[(size_t)(((br * G + gi) * TW + u) * 4 + g) * OCN_BLOCK] = sh;
-            else sab[gi][u][g] += sh;
-          }
-      HN_STAMP(9 + 8 * br);
-    }
-    // ---- xijlin, then ((share a + share b) + share c) + folded bias on this wave's tiles --------------------------------
-    const char *px = panel(P_X0), *pc = panel(P_MC);
-    if (br0 != 2) x_rows(2);
-    HN::template operand<true>(ob, y, scal[1 + P_X0], inv, red, w, lane);
-    HN_STAMP(18);
-    HN::template layer<false>(acc, ob, fr, vo, px, pc);
-    HN_STAMP(19);
-    HN::template bias<!LN>(y, acc, inv, vec + V_B0X * H, w, hh);
-    if constexpr (LN) HN::ln_relu(y, vec + V_GX * H, vec + V_EX * H, a.eps, red, w, hh, lane);
-    HN_STAMP(20);
-    HN::template operand<false>(ob, y, scal[1 + P_MC], inv, red, w, lane);
-    HN_STAMP(21);
-    HN::template layer<true>(acc, ob, fr, vo, pc, pc);
-    HN_STAMP(22);
+      for (int g = 0; g < 4; ++g) s4 += y[u][g];
+    HN::cross_put(red, HN::quarter(s4), w, lane);
+    __syncthreads();
+    const float nmean = -(HN::cross_sum(red, lane) * (1.0f / (float)H));
+    f32x4 q4 = (f32x4)(0.f);
 #pragma unroll
     for (int u = 0; u < TW; ++u)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 bf = HN::vld(vec + V_BF * H + 32 * (w * TW + u) + 8 * g, 4u * hh);
-        f32x4 ca, cb;
-        if constexpr (PARK) {
-          if (!wgA) ca = ck[(size_t)(4 * (w * TW + u) + g) * 64];
-          if (!wgB) cb = ck[(size_t)(4 * NT + 4 * (w * TW + u) + g) * 64];
-        }
-#pragma unroll
-        for (int gi = 0; gi < G; ++gi) {
-          f32x4 ab;
-          if constexpr (PARK) {
-            const f32x4 pa = wgA ? park[(size_t)((gi * TW + u) * 4 + g) * OCN_BLOCK] : ca;
-            const f32x4 pb = wgB ? park[(size_t)(((G + gi) * TW + u) * 4 + g) * OCN_BLOCK] : cb;
-            ab = pa + pb;
-          } else ab = sab[gi][u][g];
-          y[gi][u][g] = (ab + HD_GRP(acc[gi][u], g) * (f32x4)(inv[gi])) + bf;
-        }
+        const f32x4 dd = y[u][g] + (f32x4)(nmean);
+        q4 = __builtin_elementwise_fma(dd, dd, q4);
       }
-    // ---- lin: LayerNorm, ReLU, Linear(H, 1) -----------------------------------------------------------------------------
-    const float* dw = vec + V_DOTW * H;
-    f32x4 d4[G];
-#pragma unroll
-    for (int gi = 0; gi < G; ++gi) d4[gi] = (f32x4)(0.f);
-    if constexpr (LN) {
-      float nmean[G], rstd[G];
-#pragma unroll
-      for (int gi = 0; gi < G; ++gi) {
-        f32x4 s4 = (f32x4)(0.f);
-#pragma unroll
-        for (int u = 0; u < TW; ++u)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) s4 += y[gi][u][g];
-        HN::cross_put(HN::red_of(red, gi, 0), hd_quarter(s4), w, lane);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int gi = 0; gi < G; ++gi) {
-        nmean[gi] = -(HN::cross_sum(HN::red_of(red, gi, 0), lane) * (1.0f / (float)H));
-        f32x4 q4 = (f32x4)(0.f);
-#pragma unroll
-        for (int u = 0; u < TW; ++u)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 dd = y[gi][u][g] + (f32x4)(nmean[gi]);
-            q4 = __builtin_elementwise_fma(dd, dd, q4);
-          }
-        HN::cross_put(HN::red_of(red, gi, 1), hd_quarter(q4), w, lane);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int gi = 0; gi < G; ++gi) rstd[gi] = rsqrtf(HN::cross_sum(HN::red_of(red, gi, 1), lane) * (1.0f / (float)H) + a.eps);
-#pragma unroll
-      for (int u = 0; u < TW; ++u)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int fo = 32 * (w * TW + u) + 8 * g;
-          const f32x4 gl = HN::vld(vec + V_GL * H + fo, 4u * hh), el = HN::vld(vec + V_EL * H + fo, 4u * hh), dv = HN::vld(dw + fo, 4u * hh);
-#pragma unroll
-          for (int gi = 0; gi < G; ++gi) {
-            f32x4 z = __builtin_elementwise_fma((y[gi][u][g] + (f32x4)(nmean[gi])) * (f32x4)(rstd[gi]), gl, el);
-            z = __builtin_elementwise_max(z, (f32x4)(0.f));
-            d4[gi] = __builtin_elementwise_fma(z, dv, d4[gi]);
-          }
-        }
-    } else {
-#pragma unroll
-      for (int u = 0; u < TW; ++u)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 dv = HN::vld(dw + 32 * (w * TW + u) + 8 * g, 4u * hh);
-#pragma unroll
-          for (int gi = 0; gi < G; ++gi) d4[gi] = __builtin_elementwise_fma(__builtin_elementwise_max(y[gi][u][g], (f32x4)(0.f)), dv, d4[gi]);
-        }
-    }
-#pragma unroll
-    for (int gi = 0; gi < G; ++gi) HN::cross_put(HN::red_of(red, gi, 2), hd_quarter(d4[gi]), w, lane);
+    HN::cross_put(red + 256, HN::quarter(q4), w, lane);
     __syncthreads();
-    if (w == 0 && hh == 0) {
+    const float rstd = rsqrtf(HN::cross_sum(red + 256, lane) * (1.0f / (float)H) + a.eps);
 #pragma unroll
-      for (int gi = 0; gi < G; ++gi) {
-        const i64 sl = slot_of(gi);
-        if (sl < a.B) a.y[a.y_row_map ? a.y_row_map[sl] : sl] = HN::cross_sum(HN::red_of(red, gi, 2), lane) + scal[0];
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int fo = 32 * (w * TW + u) + 8 * g + 4 * hh;
+        f32x4 z = __builtin_elementwise_fma((y[u][g] + (f32x4)(nmean)) * (f32x4)(rstd), hd_lds4(s_vec + V_GL * H + fo), hd_lds4(s_vec + V_EL * H + fo));
+        z = __builtin_elementwise_max(z, (f32x4)(0.f));
+        d4 = __builtin_elementwise_fma(z, hd_lds4(dw + fo), d4);
       }
-    }
-    HN_STAMP(23);
-    // (the next tile's first crossing stores to red[..][2] only after its own first barrier... which every wave reaches
-    // after reading the dot sums above: wave 0 reads them before it arrives there)
+  } else {
+#pragma unroll
+    for (int u = 0; u < TW; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        d4 = __builtin_elementwise_fma(__builtin_elementwise_max(y[u][g], (f32x4)(0.f)), hd_lds4(dw + 32 * (w * TW + u) + 8 * g + 4 * hh), d4);
   }
+  HN::cross_put(red + 512, HN::quarter(d4), w, lane);
+  __syncthreads();
+  if (w == 0 && live && hh == 0) a.y[a.y_row_map ? a.y_row_map[slot] : slot] = HN::cross_sum(red + 512, lane) + s_scal[0];
+  HN_STAMP(23);
 }
 
 // Wp[s][t][hi, lo][lane][8 halves]: k-step s = 2 tt + ss consumes accumulator tile tt, registers 8 ss .. 8 ss + 7, of
@@ -1193,50 +1069,31 @@ static int heads_launch(const HeadsArgs& a, i64 tiles, hipStream_t st) {
   return launch_status();
 }
 
-template <int NT, bool LN, int G>
+template <int NT, bool LN>
 static int heads_nsplit_launch(const HeadsArgs& a, hipStream_t st) {
   static bool raised_dev[64] = {};
   int devid = 0;
   if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= 64) return OCN_EINVAL;
   if (!raised_dev[devid]) {
-    const hipError_t e = hipFuncSetAttribute((const void*)heads_nsplit_kernel<NT, LN, G>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)HeadsN<NT, G>::LDS_BYTES);
+    const hipError_t e = hipFuncSetAttribute((const void*)heads_nsplit_kernel<NT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)HeadsN<NT>::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     raised_dev[devid] = true;
   }
-  using HN = HeadsN<NT, G>;
-  const i64 tiles = (a.B + HN::ROWS - 1) / HN::ROWS;
-  const size_t lds = HN::LDS_BYTES;
-  static_assert(G == 1 || (int64_t)HN::MAX_GRID * HN::PARK_VECS * 16 <= HD_PARK_BYTES(HN::H), "park area");
-  const i64 grid = (G > 1 && tiles > HN::MAX_GRID) ? HN::MAX_GRID : tiles;       // G = 1: one tile per workgroup (the snake's round 0)
-  hipLaunchKernelGGL((heads_nsplit_kernel<NT, LN, G>), dim3((unsigned)grid), dim3(OCN_BLOCK), lds, st, a);
+  const i64 tiles = (a.B + HeadsN<NT>::ROWS - 1) / HeadsN<NT>::ROWS;
+  hipLaunchKernelGGL((heads_nsplit_kernel<NT, LN>), dim3((unsigned)tiles), dim3(OCN_BLOCK), HeadsN<NT>::LDS_BYTES, st, a);
   return launch_status();
-}
-template <int G>
-static int heads_nsplit_dispatch(const HeadsArgs& a, int H, hipStream_t st) {
-  switch (H) {
-    case 128: return a.ln ? heads_nsplit_launch<4, true, G>(a, st) : heads_nsplit_launch<4, false, G>(a, st);
-    case 256: return a.ln ? heads_nsplit_launch<8, true, G>(a, st) : heads_nsplit_launch<8, false, G>(a, st);
-    default: return OCN_EINVAL;
-  }
 }
 
 // batches up to this many candidates take heads_nsplit_kernel (two rounds of 32-candidate workgroups on the 256 CUs: 74 against
 // 87 us with every branch on every row, 46 against 79 us with a Cora-like class mix; tools/headslat.py)
 static int64_t g_heads_small_batch = 16384;
-static int g_heads_form = 0;           // larger batches: 0 = heads_fused_kernel, 2 = the output-split form with 64 candidates per workgroup
 
 extern "C" {
 
 int64_t ocn_heads_small_batch(int64_t max_rows) {
   const int64_t prev = g_heads_small_batch;
   if (max_rows >= 0) g_heads_small_batch = max_rows;
-  return prev;
-}
-
-int32_t ocn_heads_form(int32_t form) {
-  const int32_t prev = g_heads_form;
-  if (form == 0 || form == 2) g_heads_form = form;
   return prev;
 }
 
@@ -1278,8 +1135,11 @@ int ocn_heads_fused(const OcnHeadsArgs* h, void* stream) {
   a.y = h->y; a.dump = h->dump; a.cpark = h->cpark; a.scratch = h->scratch; a.eps = h->eps; a.ln = h->ln; a.b_on_union = h->b_on_union;
   const i64 tiles = h->dump ? 1 : (h->B + HD_ROWS - 1) / HD_ROWS;
   hipStream_t st = (hipStream_t)stream;
-  if (!h->dump && h->B <= g_heads_small_batch) return heads_nsplit_dispatch<1>(a, h->H, st);
-  if (!h->dump && g_heads_form == 2) return heads_nsplit_dispatch<2>(a, h->H, st);
+  if (!h->dump && h->B <= g_heads_small_batch) switch (h->H) {
+      case 128: return h->ln ? heads_nsplit_launch<4, true>(a, st) : heads_nsplit_launch<4, false>(a, st);
+      case 256: return h->ln ? heads_nsplit_launch<8, true>(a, st) : heads_nsplit_launch<8, false>(a, st);
+      default: return OCN_EINVAL;
+    }
   switch (h->H) {
     case 128: return h->ln ? heads_launch<4, true>(a, tiles, st) : heads_launch<4, false>(a, tiles, st);
     case 256: return h->ln ? heads_launch<8, true>(a, tiles, st) : heads_launch<8, false>(a, tiles, st);

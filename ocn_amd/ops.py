@@ -910,11 +910,6 @@ def heads_small_batch(max_rows: int = -1) -> int:
     return int(_lib.lib().ocn_heads_small_batch(int(max_rows)))
 
 
-def heads_form(form: int = -1) -> int:
-    """ocn_hip.h: ocn_heads_form — 0 / 2: the form of the fused head above the small-batch bound; returns the previous one."""
-    return int(_lib.lib().ocn_heads_form(int(form)))
-
-
 @_on_device
 def heads_fused(x1: Tensor, x2: Tensor, xij: Tensor, pack: dict, ranges: Optional[Tensor], y_row_map: Optional[Tensor],
                 b_on_union: bool, scratch: Tensor, dump: Optional[Tensor] = None) -> Optional[Tensor]:

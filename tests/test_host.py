@@ -216,8 +216,8 @@ def test_adjoverlap_signature_and_unsupported_branches():
 
 
 def test_heads_kernel_isa_audit():
-    """The fused heads' k-step is hand-placed inline asm whose waits are counted by hand (heads.hip).  tools/check_heads_asm.py
-    compiles it and checks the ISA: no instruction touches the destination of an LDS read the lgkmcnt ladder has not
+    """The fused heads' k-step is hand-placed inline asm whose waits are counted by hand, and the small-batch form requests its
+    weight fragments by asm and waits for them by count (heads.hip).  tools/check_heads_asm.py compiles both and checks the ISA: no instruction touches the destination of an LDS read the lgkmcnt ladder has not
     retired, no VALU result feeds an MFMA within two wait states, no reader of an MFMA result within twelve, no scratch."""
     import importlib.util
     import os
@@ -225,7 +225,7 @@ def test_heads_kernel_isa_audit():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     problems, stats = mod.audit(mod.compile_asm())
-    assert len(stats) == 4 and all(s["mfma"] > 0 and s["ds_read"] > 0 for s in stats.values())      # H in {128, 256} x LayerNorm on / off
+    assert len(stats) == 8 and all(s["mfma"] > 0 and s["ds_read"] > 0 for s in stats.values())      # two forms x H in {128, 256} x LayerNorm on / off
     assert not problems, problems[:5]
 
 

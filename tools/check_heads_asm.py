@@ -1,5 +1,6 @@
 """Audit of the heads kernel's ISA (cdna_hip_programming.md §5.7: the compiler neither counts the memory operations of an
-asm statement nor pads its hazards).  Compiles ocn_amd/csrc/heads.hip to assembly and checks, for every heads_fused_kernel:
+asm statement nor pads its hazards).  Compiles ocn_amd/csrc/heads.hip to assembly and checks, for every heads_fused_kernel and
+heads_nsplit_kernel (whose weight fragments are requested by asm statements and waited for by counted s_waitcnt vmcnt):
 
   1. no instruction reads or writes the destination of a ds_read_b128 / global_load that the counted s_waitcnt
      lgkmcnt(N) / vmcnt(N) ladders have not yet retired (a compiler copy / spill of an in-flight register would be silent
@@ -53,7 +54,7 @@ def audit(path):
     name, body = None, []
     funcs = {}
     for line in open(path):
-        m = re.match(r"^(_Z\w*heads_fused_kernel\w*):", line)
+        m = re.match(r"^(_Z\w*heads_(?:fused|nsplit)_kernel\w*):", line)
         if m:
             name, body = m.group(1), []
             continue

@@ -49,9 +49,7 @@ def main():
 
     if "-DOCN_X_HN_STAMPS" in flags:      # s_memtime at the phase boundaries of workgroup 0 (heads.hip: HN_STAMP)
         x1, x2, xij = (torch.randn(1152, H, device=dev) for _ in range(3))
-        form = int(os.environ.get("HL_FORM", "1"))                  # 1: 32 candidates per workgroup; 2: 64, two workgroups per CU
-        ops.heads_small_batch((1 << 40) if form == 1 else 0)
-        ops.heads_form(2 if form == 2 else 0)
+        ops.heads_small_batch(1 << 40)
         with torch.no_grad():
             for _ in range(3):
                 ops.heads_fused(x1, x2, xij, pack, None, None, True, scratch)
@@ -62,7 +60,6 @@ def main():
         print("  ".join(f"{n} {st[i + 1] - st[i]}" for i, n in enumerate(names)), flush=True)
         print(f"workgroup cycles (s_memtime, 100 MHz ticks x clock ratio) {st[23] - st[0]}", flush=True)
         ops.heads_small_batch(prev)
-        ops.heads_form(0)
         return
     try:
         for B in (32, 256, 1152, 2048, 4096, 8192, 16384, 32768, 65536):
@@ -72,17 +69,15 @@ def main():
                              dtype=torch.int64, device=dev)
             for nm, ranges in (("all rows", None), ("class ranges", r)):
                 out = {}
-                for form, bound, f in (("throughput", 0, 0), ("small", 1 << 40, 0), ("split64", 0, 2)):
+                for form, bound in (("throughput", 0), ("small", 1 << 40)):
                     ops.heads_small_batch(bound)
-                    ops.heads_form(f)
                     with torch.no_grad():
                         out[form] = timed(lambda: ops.heads_fused(x1, x2, xij, pack, ranges, None, True, scratch))
-                same = torch.equal(out["throughput"][1], out["small"][1]) and torch.equal(out["throughput"][1], out["split64"][1])
+                same = torch.equal(out["throughput"][1], out["small"][1])
                 print(f"H={H} ln={a.ln} B={B:6d} {nm:12s}: 128 per workgroup {out['throughput'][0]:8.1f} us   32 per workgroup {out['small'][0]:8.1f} us"
-                      f"   64 per workgroup, two per CU {out['split64'][0]:8.1f} us   bit-equal {same}", flush=True)
+                      f"   bit-equal {same}", flush=True)
     finally:
         ops.heads_small_batch(prev)
-        ops.heads_form(0)
 
 
 if __name__ == "__main__":
