@@ -34,7 +34,8 @@ extern "C" {
  * 8: a scan whose workspace was not zero ends in OCN_SCAN_POISON totals and a status bit instead of a GPU trap; `status` is
  *    int32[4] for every intersection entry, word 3 the sticky error word; ocn_cn_weights_cn7 takes the Chebyshev diagonals,
  *    ocn_gather_schedule a segment; + ocn_cn_gather3_backward, ocn_cn_gather_backward_det_lists, ocn_ln_drop_relu_*.
- * 9: + ocn_heads_small_batch (ocn_heads_fused picks its small-batch form by the batch size; same bits). */
+ * 9: + ocn_heads_small_batch (ocn_heads_fused picks its small-batch form by the batch size; same bits), ocn_spgemm_bit_rows
+ *    (ocn_cn_flags accepts rowptrT2 == NULL beside bitmapT2). */
 #define OCN_ABI_VERSION 9
 #define OCN_EINVAL (-1)   /* null pointer / negative size / unsupported combination */
 #define OCN_ECAP   (-2)   /* reported through the device status word: flags capacity too small */
@@ -378,6 +379,14 @@ int ocn_spgemm_pattern_count(const int64_t* rowptrA, const int32_t* colA, int64_
 int ocn_spgemm_pattern_fill(const int64_t* rowptrA, const int32_t* colA, int64_t n_rows,
                             const int64_t* rowptrB, const int32_t* colB, int64_t n_colsB,
                             const int64_t* rowptrC, int32_t* colC, void* stream);
+/* Bit rows of A*B for the rows a caller is about to probe (a training step's per-batch A², NeighborOverlap_large.py:68-74, is
+ * read at the candidates' target rows only): request i names row rows[i] (int64, duplicates and out-of-range ids allowed — the
+ * latter are ignored); `done` (int32 [n_rows], zero before the first call, kept by the caller between calls) marks the rows that
+ * exist, a row is built by the request that turns its word from 0 to 1.  Rows never requested stay unwritten.  ocn_cn_flags
+ * takes such a T2 with rowptrT2 == NULL (n_cols > 8192 only: small graphs read the row lengths too). */
+int ocn_spgemm_bit_rows(const int64_t* rowptrA, const int32_t* colA, int64_t n_rows, const int64_t* rowptrB, const int32_t* colB,
+                        int64_t n_colsB, const int64_t* rows, int64_t n_req, int32_t* done, uint32_t* bitmap,
+                        int64_t bm_stride_words, void* stream);
 
 /* The block route of utils.block_matrix_multiply (utils.py:287-323; the drivers' --adj2byblock, ogbl-ddi): A as a dense
  * 0/1 int8 matrix (ocn_dense_from_csr: dense[r][c] and its transpose, row stride ld bytes, ld a multiple of 64 >= n, both

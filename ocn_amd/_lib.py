@@ -75,6 +75,7 @@ SIGNATURES = {
     "ocn_spgemm_max_cols": (c_int64, []),
     "ocn_spgemm_pattern_count": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P]),
     "ocn_spgemm_pattern_fill": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, _P, _P]),
+    "ocn_spgemm_bit_rows": (c_int32, [_P, _P, c_int64, _P, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P]),
     "ocn_dense_from_csr": (c_int32, [_P, _P, c_int64, c_int64, _P, _P, _P]),
     "ocn_dense_block_mm_bits": (c_int32, [_P, _P, c_int64, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_int64, _P]),
     "ocn_bitrows_from_csr": (c_int32, [_P, _P, c_int64, _P, c_int64, _P]),

@@ -1676,7 +1676,8 @@ int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* row
       (const unsigned*)bitmapT1, (i64)bm1_stride_words, (const unsigned*)bitmapT2, (i64)bm_stride_words, (const i64*)src, \
       (const i64*)dst, (const i64*)order, (i64)B, (i64)n_cols, (const i64*)off, flags, (i64)flags_cap, \
       (u64*)hist, cnt1, cnt2, status, (u64*)rec, gcost
-  if (rowptrT2) {
+  if (!rowptrT2 && bitmapT2 && lh) return OCN_EINVAL;      // (small graphs read T2's row lengths beside its bit rows)
+  if (rowptrT2 || bitmapT2) {                              // T2 by its bit rows alone: a product whose rows are built on demand
     if (lh) hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, true, true>), dim3(grid), dim3(OCN_BLOCK), lds, st,
                                CN_FLAGS_ARGS(rowptrT2, colT2));
     else hipLaunchKernelGGL((cn_flags_kernel<OCN_X_G, true, false>), dim3(grid), dim3(OCN_BLOCK), 0, st,

@@ -59,7 +59,64 @@ __global__ __launch_bounds__(OCN_BLOCK) void spgemm_pattern_kernel(
   }
 }
 
+extern "C" int64_t ocn_spgemm_max_cols(void);
+
+// Bit rows of A*B for the rows somebody asks for (a training step's per-batch A² is probed at the candidates' target rows
+// only — two fifths of the rows at the collab shape, and a 29 KiB dense row is what the counting pass pays for each):
+// request i names row rows[i]; whoever turns done[row] from 0 to 1 builds it, duplicates and rows of earlier requests skip.
+__global__ __launch_bounds__(OCN_BLOCK) void spgemm_rows_kernel(
+    const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA, i64 n_rows,
+    const i64* __restrict__ rowptrB, const int32_t* __restrict__ colB, i64 n_colsB,
+    const i64* __restrict__ rows, i64 n_req, int32_t* __restrict__ done,
+    unsigned* __restrict__ bitmap_out, i64 bm_stride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned bm[];
+  __shared__ int s_mine;
+  const int words = (int)((n_colsB + 31) >> 5);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int w = threadIdx.x; w < words; w += OCN_BLOCK) bm[w] = 0u;
+  for (i64 i = blockIdx.x; i < n_req; i += gridDim.x) {
+    const i64 r = rows[i];
+    if (threadIdx.x == 0) s_mine = (r >= 0 && r < n_rows && atomicExch(&done[r], 1) == 0) ? 1 : 0;
+    __syncthreads();                                        // (also: the bitmap is zero)
+    const int mine = s_mine;
+    __syncthreads();
+    if (!mine) continue;
+    const i64 a0 = rowptrA[r], da = rowptrA[r + 1] - a0;
+    for (i64 q = wave; q < da; q += OCN_WPB) {
+      const i64 m = colA[a0 + q];
+      const i64 b0 = rowptrB[m], db = rowptrB[m + 1] - b0;
+      for (i64 t = lane; t < db; t += OCN_WAVE) {
+        const unsigned k = (unsigned)colB[b0 + t];
+        atomicOr(&bm[k >> 5], 1u << (k & 31u));
+      }
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < words; w += OCN_BLOCK) {
+      bitmap_out[r * bm_stride + w] = bm[w];
+      bm[w] = 0u;
+    }
+  }
+}
+
 extern "C" {
+
+int ocn_spgemm_bit_rows(const int64_t* rowptrA, const int32_t* colA, int64_t n_rows, const int64_t* rowptrB, const int32_t* colB,
+                        int64_t n_colsB, const int64_t* rows, int64_t n_req, int32_t* done, uint32_t* bitmap,
+                        int64_t bm_stride_words, void* stream) {
+  if (n_rows < 0 || n_req < 0 || n_colsB <= 0 || n_colsB > ocn_spgemm_max_cols()) return OCN_EINVAL;
+  if (n_req == 0 || n_rows == 0) return 0;
+  if (!rowptrA || !rowptrB || !rows || !done || !bitmap || bm_stride_words < (n_colsB + 31) / 32) return OCN_EINVAL;
+  const size_t lds = (size_t)(((n_colsB + 31) >> 5) * 4);
+  const int per_cu = (int)((160 * 1024) / (lds + 256));
+  int64_t grid = 256 * (per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu));
+  if (grid > n_req) grid = n_req;
+  const hipError_t err = hipFuncSetAttribute((const void*)spgemm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (err != hipSuccess) return (int)err;
+  hipLaunchKernelGGL(spgemm_rows_kernel, dim3((unsigned)grid), dim3(OCN_BLOCK), lds, (hipStream_t)stream,
+                     (const i64*)rowptrA, colA, (i64)n_rows, (const i64*)rowptrB, colB, (i64)n_colsB, (const i64*)rows, (i64)n_req,
+                     done, (unsigned*)bitmap, (i64)bm_stride_words);
+  return launch_status();
+}
 
 int64_t ocn_spgemm_max_cols(void) { return (int64_t)SPGEMM_MAX_LDS * 8; }
 

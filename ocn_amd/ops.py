@@ -256,7 +256,8 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     if not walk:
         _req(t1[0], torch.int64, "rowptrT1", 1); _req(t1[1], torch.int32, "colT1", 1)
         if t2 is not None:
-            _req(t2[0], torch.int64, "rowptrT2", 1)
+            if t2[0] is not None or t2_bitmap is None or n_cols <= LH_MAX_COLS:      # (a product with rows on demand: bit rows only)
+                _req(t2[0], torch.int64, "rowptrT2", 1)
             if t2[1] is not None or t2_bitmap is None:           # (with bit rows the kernel never reads T2's column ids: they may be deferred)
                 _req(t2[1], torch.int32, "colT2", 1)
     _req(src, torch.int64, "src", 1); _req(dst, torch.int64, "dst", 1)
@@ -322,7 +323,7 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     else:
         if t2_bitmap is not None:
             _req(t2_bitmap, torch.int32, "t2_bitmap", 2)
-            if t2 is None or t2_bitmap.shape[0] != t2[0].numel() - 1 or t2_bitmap.shape[1] * 32 < n_cols:
+            if t2 is None or (t2[0] is not None and t2_bitmap.shape[0] != t2[0].numel() - 1) or t2_bitmap.shape[1] * 32 < n_cols:
                 raise ValueError("t2_bitmap does not match the T2 adjacency")
         if t1_bitmap is not None:
             _req(t1_bitmap, torch.int32, "t1_bitmap", 2)
@@ -713,6 +714,30 @@ def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int, defer_fill: bool
     if defer_fill and bitmap is not None:
         return rowptrC, fill, bitmap
     return rowptrC, fill(), bitmap
+
+
+LH_MAX_COLS = 8192                # cn_stage.hip: up to this many columns the intersection pass reads T2's row lengths beside its bit rows
+lazy_product_rows = os.environ.get("OCN_LAZY_PRODUCT", "1") != "0"     # a product formed under autograd builds its bit rows on demand (sparse._lazy_product)
+
+
+def spgemm_max_cols() -> int:
+    return int(_lib.lib().ocn_spgemm_max_cols())
+
+
+@_on_device
+def spgemm_bit_rows(rowptrA, colA, rowptrB, colB, n_cols_b: int, rows: Tensor, done: Tensor, bitmap: Tensor) -> None:
+    """ocn_hip.h: ocn_spgemm_bit_rows — the dense bit rows ``rows`` (int64 ids) of A·B that ``done`` (int32 per row) does not
+    mark yet, into ``bitmap`` [n_rows, words]; on the current stream."""
+    _req(rowptrA, torch.int64, "rowptrA", 1); _req(colA, torch.int32, "colA", 1)
+    _req(rowptrB, torch.int64, "rowptrB", 1); _req(colB, torch.int32, "colB", 1)
+    _req(rows, torch.int64, "rows", 1); _req(done, torch.int32, "done", 1); _req(bitmap, torch.int32, "bitmap", 2)
+    n = rowptrA.numel() - 1
+    if done.numel() != n or bitmap.shape[0] != n or bitmap.shape[1] * 32 < n_cols_b:
+        raise ValueError("spgemm_bit_rows: done / bitmap do not match the product")
+    _mark("begin")
+    check(_lib.lib().ocn_spgemm_bit_rows(ptr(rowptrA), ptr(colA), n, ptr(rowptrB), ptr(colB), n_cols_b, ptr(rows), rows.numel(),
+                                         ptr(done), ptr(bitmap), bitmap.shape[1], stream_ptr()), "ocn_spgemm_bit_rows")
+    _mark("adj2_rows")
 
 
 dense_adj2_max_nodes = 32768      # block route: A as a dense int8 matrix (n^2 bytes, twice) up to this many nodes

@@ -66,6 +66,8 @@ def score_edges(predictor, h: Tensor, adj, adj2, edges: Tensor, batch_size: int,
     # the adjacency's lazy caches (bit rows, longest row) are built HERE, on the caller's stream, before the loop forks its
     # side streams: two phase-A streams must never race on a half-built cache (the caches also carry their own events)
     adj.warm(walk=False)
+    if adj2 is not None and adj2.rows_on_demand():          # (a product formed under autograd: its rows are built on ONE stream)
+        adj2.product_bit_rows()
     # the ids of the whole split are bounds-checked once; the batches then run without a host sync each
     with ops.prevalidated(edges[:, 0], edges[:, 1], adj.size(0), adj.size(0)):
         perms = list(PermIterator(edges.device, edges.shape[0], batch_size, training=False))

@@ -110,9 +110,54 @@ class SparseTensor:
     # A² of the masked graph per batch, NeighborOverlap_large.py:68-74) runs when somebody actually asks for the ids.
     @property
     def _col(self) -> Tensor:
+        if self._col_v is None and self._col_thunk is None and getattr(self, "_lazy", None) is not None:
+            self._complete()
         if self._col_v is None and self._col_thunk is not None:
             self._col_v, self._col_thunk = self._col_thunk(), None
         return self._col_v
+
+    # One step further for a product formed while autograd records (a training step's per-batch A²): not even the counting pass
+    # runs before somebody needs the row pointers — the intersection pass of a large graph asks for the bit rows of its candidates'
+    # TARGET rows only (``product_bit_rows(rows)``: ocn_hip.h, ocn_spgemm_bit_rows), two fifths of the rows at the collab shape, and
+    # every dense row costs a 29 KiB write.  Anything that treats the product as a matrix (row pointers, ids, nnz, all bit rows)
+    # completes it with the ordinary counting pass.  Single-stream use only (the loops that fork streams warm() first = complete).
+    @property
+    def _rowptr(self) -> Tensor:
+        if self._rowptr_v is None and getattr(self, "_lazy", None) is not None:
+            self._complete()
+        return self._rowptr_v
+
+    @_rowptr.setter
+    def _rowptr(self, v) -> None:
+        self._rowptr_v = v
+
+    def _complete(self) -> None:
+        a_rp, a_col, b_rp, b_col = self._lazy
+        self._lazy = self._done = self._bitmap = None               # (the partial bit rows go before the full ones come)
+        rowptr, col, bitmap = ops.spgemm_pattern(a_rp, a_col, b_rp, b_col, self._sizes[1], defer_fill=True)
+        self._rowptr_v = rowptr
+        if callable(col):
+            self._col_v, self._col_thunk = None, col
+        else:
+            self._col_v, self._col_thunk = col, None
+        self._bitmap = bitmap
+        if bitmap is not None:
+            self._published("bitmap")
+
+    @classmethod
+    def _lazy_product(cls, a: "SparseTensor", b: "SparseTensor") -> "SparseTensor":
+        out = cls.__new__(cls)
+        out._sizes = (int(a._sizes[0]), int(b._sizes[1]))
+        out._rowptr_v = None
+        out._col_v = out._col_thunk = None
+        out._value = None
+        out._row_cache = out._maxdeg = out._nds = None
+        out._ready = {}
+        out._lazy = (a._rowptr, a._col, b._rowptr, b._col)
+        dev = a._rowptr.device
+        out._bitmap = torch.empty(out._sizes[0], (out._sizes[1] + 31) // 32, dtype=torch.int32, device=dev)      # rows on demand
+        out._done = torch.zeros(out._sizes[0], dtype=torch.int32, device=dev)
+        return out
 
     @_col.setter
     def _col(self, v) -> None:
@@ -182,7 +227,7 @@ class SparseTensor:
         return int(self._col.numel())
 
     def device(self):
-        return self._rowptr.device
+        return self._bitmap.device if getattr(self, "_lazy", None) is not None else self._rowptr.device
 
     def has_value(self) -> bool:
         return self._value is not None
@@ -230,6 +275,8 @@ class SparseTensor:
         """The pattern as dense bit rows (cached, built once by ocn_bitrows_from_csr) when they fit
         ``ops.a1_bitmap_max_bytes``, else None: what the intersection kernel probes instead of searching a row
         (a product of ``matmul`` arrives with its bit rows already)."""
+        if getattr(self, "_lazy", None) is not None:        # (a product with rows on demand, asked for ALL its rows)
+            self._complete()
         if self._bitmap is None and self._rowptr.is_cuda:
             n, m = self._sizes
             if 0 < n * ((m + 31) // 32) * 4 <= ops.a1_bitmap_max_bytes:
@@ -249,12 +296,25 @@ class SparseTensor:
             self._await("nds")
         return self._nds
 
-    def product_bit_rows(self) -> Optional[Tensor]:
+    def product_bit_rows(self, rows: Optional[Tensor] = None) -> Optional[Tensor]:
         """The bit rows this matrix ARRIVED with (``A @ A``, the block route), never built on demand: A² of a large graph
-        only has them when they fit ``ops.a2_bitmap_max_bytes`` at construction."""
+        only has them when they fit ``ops.a2_bitmap_max_bytes`` at construction.  ``rows`` (int64 ids): the caller will probe
+        these rows only — a product whose rows are built on demand (``_lazy_product``) builds the missing ones of them now, on
+        the current stream."""
+        if getattr(self, "_lazy", None) is not None:
+            if rows is None:
+                self._complete()
+            else:
+                a_rp, a_col, b_rp, b_col = self._lazy
+                ops.spgemm_bit_rows(a_rp, a_col, b_rp, b_col, self._sizes[1], rows, self._done, self._bitmap)
+                return self._bitmap
         if self._bitmap is not None:
             self._await("bitmap")
         return self._bitmap
+
+    def rows_on_demand(self) -> bool:
+        """A product none of whose matrix-level data exists yet (see ``_lazy_product``)."""
+        return getattr(self, "_lazy", None) is not None
 
     def warm(self, walk: bool = False) -> None:
         """Build the lazy caches a candidate batch reads (bit rows, longest row, the walk route's degree sums) on the
@@ -417,6 +477,10 @@ class CooView:
         a, b = self.sp, other.sp
         if a._sizes[1] != b._sizes[0]:
             raise ValueError("shape mismatch in sparse @ sparse")
+        n, m = a._sizes[0], b._sizes[1]
+        if (ops.lazy_product_rows and torch.is_grad_enabled() and a._rowptr.is_cuda and m > ops.LH_MAX_COLS
+                and 0 < n * ((m + 31) // 32) * 4 <= ops.a2_bitmap_max_bytes and m <= ops.spgemm_max_cols()):
+            return CooView(SparseTensor._lazy_product(a, b), is_product=True)
         rowptr, col, bitmap = ops.spgemm_pattern(a._rowptr, a._col, b._rowptr, b._col, b._sizes[1], defer_fill=True)
         if callable(col):                      # (bit rows exist: the column ids wait until somebody reads them)
             out = SparseTensor._deferred_product(rowptr, col, bitmap, (a._sizes[0], b._sizes[1]))

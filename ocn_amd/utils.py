@@ -69,11 +69,16 @@ class CNState:
         # ... and what each group of four slots will cost the pooling, for its longest-first schedule (+ room for the schedule)
         self.sched = (ops.buf(ws, "sched", 2 * ((self.B + 3) // 4), torch.int32, self.src.device)
                       if (self.rec is not None and ops.heavy_first and self.B >= ops.sort_edges_min_batch) else None)
+        # a product whose rows are built on demand (a training step's A²): the rows this batch probes, and no row pointers — on
+        # one stream only (a loop with several phase-A streams completes the product before it forks them: pipeline.score_edges)
+        t2_rows = (t2 is not None and not walk and t2.rows_on_demand() and not getattr(ops, "_overlap_active", False))
         (self.order, self.off, self.flags, self.wc, self.hist, self.cnt1, self.cnt2, self.status, self.scal) = ops.cn_flags(
             adj._rowptr, adj._col, None if walk else (t1._rowptr, t1._col),
-            None if (walk or t2 is None) else (t2._rowptr, t2._col if (t2.col_materialized() or t2._bitmap is None) else None),
+            None if (walk or t2 is None) else ((None, None) if t2_rows else
+                                               (t2._rowptr, t2._col if (t2.col_materialized() or t2._bitmap is None) else None)),
             self.src, self.dst, self.N,
-            adj.max_rowcount(), walk=walk, t2_bitmap=None if (walk or t2 is None) else t2.product_bit_rows(), wsd=ws,
+            adj.max_rowcount(), walk=walk,
+            t2_bitmap=None if (walk or t2 is None) else (t2.product_bit_rows(self.dst) if t2_rows else t2.product_bit_rows()), wsd=ws,
             nds=adj.neighbor_degree_sum() if (walk and ops.walk_two_sided) else None,
             t1_bitmap=None if walk else t1.bit_rows(), rec=self.rec, sched=self.sched)
         self._hist_live = True

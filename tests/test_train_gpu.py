@@ -234,6 +234,48 @@ def test_product_column_ids_are_deferred_until_read(hiplib):
     assert r.cpu().tolist() == oadj2.row.tolist() and c.cpu().tolist() == oadj2.col.tolist()
 
 
+def test_product_rows_are_built_on_demand_under_autograd(hiplib, monkeypatch):
+    """A @ A formed while autograd records, on a graph past the small-graph histogram (N > 8192): nothing is computed until
+    somebody needs it.  The intersection pass asks for the bit rows of its candidates' TARGET rows (ocn_spgemm_bit_rows: each
+    row built once, duplicates and later batches skip it) and gets the same flags, counts and histograms as from the whole
+    product; anything that treats the product as a matrix completes it — the eager product's row pointers, ids and bit rows."""
+    from ocn_amd.utils import CNState
+    from tests.helpers import batch, make_graph, to_product
+    n = 12000
+    oadj = make_graph(n, 10, 300, seed=5, isolated=40)
+    adj = to_product(oadj, DEV)
+    sp = adj.to_torch_sparse_coo_tensor()
+    assert torch.is_grad_enabled()
+    lazy = SparseTensor.from_torch_sparse_coo_tensor(sp @ sp, False)
+    assert lazy.rows_on_demand() and lazy.sizes() == [n, n] and lazy.device() == adj.device()
+    with torch.no_grad():
+        full = SparseTensor.from_torch_sparse_coo_tensor(sp @ sp, False)
+    assert not full.rows_on_demand() and full._bitmap is not None
+    e1, e2 = batch(oadj, 4096, 7).to(DEV), batch(oadj, 3000, 8).to(DEV)
+    e2[1, :100] = e1[1, :100]                                   # rows of the first batch again
+    e2[1, 100:200] = e2[1, 100]                                 # duplicates inside a batch
+    seen = torch.zeros(n, dtype=torch.bool, device=DEV)
+    for e in (e1, e2):
+        st, ref = CNState(adj, adj, lazy, e), CNState(adj, adj, full, e)
+        assert lazy.rows_on_demand()                            # the intersection pass did not complete it
+        assert torch.equal(st.off, ref.off) and torch.equal(st.flags[: int(st.off[-1])], ref.flags[: int(ref.off[-1])])
+        assert torch.equal(st.cnt1, ref.cnt1) and torch.equal(st.cnt2, ref.cnt2) and torch.equal(st.hist, ref.hist)
+        seen[e[1]] = True
+        assert torch.equal(lazy._done.bool(), seen)             # exactly the requested rows exist ...
+        assert torch.equal(lazy._bitmap[seen], full._bitmap[seen])      # ... and they are the product's
+    assert int(seen.sum()) < n // 2
+    monkeypatch.setattr(ops, "_overlap_active", True)           # a loop with several phase-A streams: the whole product, once
+    st = CNState(adj, adj, lazy, e1)
+    monkeypatch.setattr(ops, "_overlap_active", False)
+    assert not lazy.rows_on_demand() and torch.equal(st.hist, CNState(adj, adj, full, e1).hist)
+    assert torch.equal(lazy._rowptr, full._rowptr) and torch.equal(lazy._bitmap, full._bitmap)
+    assert lazy.nnz() == full.nnz() and torch.equal(lazy._col, full._col)
+    lazy2 = SparseTensor.from_torch_sparse_coo_tensor(sp @ sp, False)                # completed by a matrix-level read
+    assert lazy2.rows_on_demand() and lazy2.nnz() == full.nnz() and not lazy2.rows_on_demand()
+    monkeypatch.setattr(ops, "lazy_product_rows", False)
+    assert not SparseTensor.from_torch_sparse_coo_tensor(sp @ sp, False).rows_on_demand()
+
+
 @pytest.mark.parametrize("H,rows", [(32, 1000), (64, 4097), (256, 20000), (512, 333), (16, 70000)])
 @pytest.mark.parametrize("ln,relu,p", [(True, True, 0.0), (True, True, 0.3), (False, True, 0.05), (True, False, 0.0), (False, False, 0.5)])
 def test_ln_dropout_relu_tail_matches_torch_autograd(hiplib, H, rows, ln, relu, p):
