@@ -968,7 +968,7 @@ __device__ __forceinline__ void chain_rows(const float2* __restrict__ w, const f
 #pragma unroll
     for (int u = 0; u < BLK; ++u)
 #pragma unroll
-      for (int q = 0; q < FPL; ++q) axpy_pair(acc[q], f32x2{w8[u].x, w8[u].y}, x8[u][q]);
+      for (int q = 0; q < FPL; ++q) axpy_pair_scalar(acc[q], f32x2{w8[u].x, w8[u].y}, x8[u][q]);
   };
   const int nb = nr / BLK;                   // blocks of BLK entries, two register sets: block b + 1 is read while b is added
   if (nb > 0) {
@@ -987,7 +987,7 @@ __device__ __forceinline__ void chain_rows(const float2* __restrict__ w, const f
   for (int r = nb * BLK; r < nr; ++r) {
     const float2 wr = w[r];
 #pragma unroll
-    for (int q = 0; q < FPL; ++q) axpy_pair(acc[q], f32x2{wr.x, wr.y}, xs[r * HF + q]);
+    for (int q = 0; q < FPL; ++q) axpy_pair_scalar(acc[q], f32x2{wr.x, wr.y}, xs[r * HF + q]);
   }
 #pragma unroll
   for (int q = 0; q < FPL; ++q) { acc1[q] = acc[q].x; acc2[q] = acc[q].y; }
@@ -1002,7 +1002,25 @@ __device__ __forceinline__ void chain_rows(const float2* __restrict__ w, const f
 // LONG: the same kernel over the batch rows whose source row is LONGER than LONG_ROW only (large batches of narrow
 // embeddings on a dense graph — ogbl-ddi: a third of the candidates have such a source; a lane group of the packed
 // kernel would walk 2 000 positions four gathers at a time).
-template <int LPE, int NV, bool LONG = false, int WPB = (LONG ? 1 : OCN_WPB)>
+#ifdef OCN_X_WAVE_CHECK
+__device__ unsigned g_wave_chk_n;
+__device__ float g_wave_chk[4096 * 6];
+extern "C" int ocn_debug_wave_check(float* out, unsigned* n) {
+  const int e = (int)hipMemcpyFromSymbol(n, HIP_SYMBOL(g_wave_chk_n), sizeof(unsigned));
+  return e ? e : (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wave_chk), sizeof(float) * 4096 * 6);
+}
+#endif
+// (waves per workgroup: the slabs of four waves at H = 64 are 70 KiB of static LDS — above the 64 KiB a workgroup gets without an
+// opt-in, and measured to go wrong exactly then: with workgroups of ANOTHER kernel on the same CU (a scoring loop's heads beside
+// this pooling on a second stream) about one batch in a hundred came back with 64 bytes of one xcn1 row wrong; two waves there)
+template <int LPE, int NV, bool LONG>
+#ifdef OCN_X_WAVE_WPB   /* diagnostic build only (tools/dbg_two_stream.py) */
+constexpr int gather_wave_wpb() { return LONG ? 1 : OCN_X_WAVE_WPB; }
+#else
+constexpr int gather_wave_wpb() { return LONG ? 1 : ((size_t)OCN_WPB * OCN_WAVE * (LPE * NV * 16 + 24) > 65536 ? 2 : OCN_WPB); }
+#endif
+
+template <int LPE, int NV, bool LONG = false, int WPB = gather_wave_wpb<LPE, NV, LONG>()>
 __global__ __launch_bounds__(WPB * OCN_WAVE) void cn_gather_wave_kernel(
     const i64* __restrict__ rowptrA, const int32_t* __restrict__ colA,
     const i64* __restrict__ src, const i64* __restrict__ dst, const i64* __restrict__ order, i64 B,
@@ -1100,6 +1118,30 @@ __global__ __launch_bounds__(WPB * OCN_WAVE) void cn_gather_wave_kernel(
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     n = n_next;
   }
+#ifdef OCN_X_WAVE_CHECK   /* diagnostic build only (tools/dbg_two_stream.py): the same sums once more, straight from memory */
+  if (!LONG && lane < HF) {
+    float c1 = 0.f, c2 = 0.f;
+    for (i64 p = 0; p < da; ++p) {
+      const unsigned f = flags[base + p] & fmask;
+      if (!f) continue;
+      const int32_t k = colA[a0 + p];
+      float wa = 0.f, wb = 0.f;
+      entry_weights(f, weights[k], wc ? (float)wc[base + p] : 1.f, wa, wb);
+      if (wa == 0.f && wb == 0.f) continue;
+      const float xv = h[(i64)k * H + lane];
+      c1 = __fadd_rn(c1, __fmul_rn(wa, xv));
+      c2 = __fadd_rn(c2, __fmul_rn(wb, xv));
+    }
+    const bool bad1 = __float_as_uint(c1) != __float_as_uint(acc1[0]), bad2 = !full2 && __float_as_uint(c2) != __float_as_uint(acc2[0]);
+    if (bad1 || bad2) {
+      const unsigned q = atomicAdd(&g_wave_chk_n, 1u);
+      if (q < 4096) {
+        g_wave_chk[q * 6 + 0] = (float)e; g_wave_chk[q * 6 + 1] = (float)lane; g_wave_chk[q * 6 + 2] = acc1[0];
+        g_wave_chk[q * 6 + 3] = c1; g_wave_chk[q * 6 + 4] = acc2[0]; g_wave_chk[q * 6 + 5] = c2;
+      }
+    }
+  }
+#endif
   if (lane < HF) {
     const i64 o = (out_row ? out_row[e] : e) * H + lane;
     xcn1[o] = acc1[0];
@@ -1573,8 +1615,9 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
   bool packed = true;
   if constexpr (LPE <= 16) {
     if (B * LPE < 262144) {                  // the packed form would not fill the SIMDs
-      hipLaunchKernelGGL((cn_gather_wave_kernel<LPE, NV>), dim3((unsigned)((B + OCN_WPB - 1) / OCN_WPB)),
-                         dim3(OCN_BLOCK), 0, st, (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst,
+      constexpr int WW = gather_wave_wpb<LPE, NV, false>();
+      hipLaunchKernelGGL((cn_gather_wave_kernel<LPE, NV>), dim3((unsigned)((B + WW - 1) / WW)),
+                         dim3(WW * OCN_WAVE), 0, st, (const i64*)rowptrA, colA, (const i64*)src, (const i64*)dst,
                          (const i64*)order, (i64)B, (const i64*)off, flags, wc, (const float4*)weights, h, (int)H,
                          xcn1, xcn2, xij, (const i64*)out_row, cnt2, rowsum);
       packed = false;

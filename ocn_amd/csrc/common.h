@@ -130,6 +130,15 @@ __device__ __forceinline__ void axpy_pair(f32x2& a, const f32x2 w, const float x
   const f32x2 p = w * xx;
   a = a + p;
 }
+// The same two roundings as two scalar chains.  For sums whose x comes out of LDS one float at a time (chain_rows): there the
+// packed form compiles to `v_pk_mul_f32 v[w:w+1], v[x:x+1] op_sel_hi:[1,0]` with an UNDEFINED high register, and the H = 64 wave
+// kernel — all 64 lanes summing — returned wrong sums in lanes 48..63 of the .x half about once in a hundred batches whenever
+// another kernel (a scoring loop's heads on a second stream) ran beside it: DESIGN.md §6, tools/dbg_two_stream.py.  In-kernel
+// check: the scalar form never, 0 of 3 000 batches.
+__device__ __forceinline__ void axpy_pair_scalar(f32x2& a, const f32x2 w, const float x) {
+  a[0] = __fadd_rn(a[0], __fmul_rn(w[0], x));
+  a[1] = __fadd_rn(a[1], __fmul_rn(w[1], x));
+}
 
 __device__ __forceinline__ void axpy4(float4& acc, float w, const float4& x) {
   acc.x = __fadd_rn(acc.x, __fmul_rn(w, x.x));

@@ -228,3 +228,43 @@ def test_graph_replayed_scoring_loop_equals_the_eager_loop(hiplib, monkeypatch, 
     ref = run()
     torch.cuda.synchronize()
     assert torch.equal(got, ref)
+
+
+def test_two_stream_loop_under_stress_at_every_pooling_width(hiplib):
+    """Round 4 found the H = 64 wave pooling kernel returning 64 wrong bytes of one xcn1 row about once in a hundred batches — only
+    while another stream's heads ran beside it, so no single-stream test saw it (packed f32 multiply-add with an undefined high source
+    register in chain_rows; now two scalar chains: cn_stage.hip).  Thirty repetitions of the depth-2 loop per
+    width, every batch against the one-stream loop: a fault at that rate fails this test nine times in ten."""
+    from types import SimpleNamespace
+    from ocn_amd.model import predictor_dict
+    from ocn_amd.pipeline import overlapped_steps
+    from ocn_amd.utils import adjoverlap
+    from tests.helpers import batch, make_graph, product_adj2, to_product
+    n, B = 20000, 8192
+    oadj = make_graph(n, 10, 600, 3, isolated=100)
+    adj = to_product(oadj, DEV)
+    with torch.no_grad():
+        adj2 = product_adj2(adj)
+    e0 = batch(oadj, B, 53).to(DEV)
+    g = torch.Generator().manual_seed(9)
+    batches = [e0[:, torch.randperm(B, generator=g).to(DEV)][:, : B - 5 * q].contiguous() for q in range(12)]
+    args = SimpleNamespace(sum=0.7)
+    for H in (64, 32, 128):
+        torch.manual_seed(8 + H)
+        x = torch.randn(n, H, device=DEV)
+        pred = predictor_dict["cn5"](H, H, 1, 3, 0.0, 0.0, True).to(DEV).eval()
+        pred.innerprod.fill_(0.37)
+
+        def begin(it):
+            e = batches[it]
+            return pred.begin(x, adj, adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e), e, slot=it, args=args)
+
+        def run(overlap):
+            return [o.clone() for o in overlapped_steps(begin, lambda tok: pred.finish(x, tok, args), len(batches), overlap=overlap)]
+        with torch.no_grad():
+            base = run(False)
+            for rep in range(30 if H == 64 else 8):
+                outs = run(True)
+                torch.cuda.synchronize()
+                bad = [(i, int((a != b).sum())) for i, (a, b) in enumerate(zip(outs, base)) if not torch.equal(a, b)]
+                assert not bad, (H, rep, bad)
