@@ -968,7 +968,7 @@ __device__ __forceinline__ void chain_rows(const float2* __restrict__ w, const f
 #pragma unroll
     for (int u = 0; u < BLK; ++u)
 #pragma unroll
-      for (int q = 0; q < FPL; ++q) axpy_pair_scalar(acc[q], f32x2{w8[u].x, w8[u].y}, x8[u][q]);
+      for (int q = 0; q < FPL; ++q) axpy_pair_lds(acc[q], f32x2{w8[u].x, w8[u].y}, x8[u][q]);
   };
   const int nb = nr / BLK;                   // blocks of BLK entries, two register sets: block b + 1 is read while b is added
   if (nb > 0) {
@@ -987,7 +987,7 @@ __device__ __forceinline__ void chain_rows(const float2* __restrict__ w, const f
   for (int r = nb * BLK; r < nr; ++r) {
     const float2 wr = w[r];
 #pragma unroll
-    for (int q = 0; q < FPL; ++q) axpy_pair_scalar(acc[q], f32x2{wr.x, wr.y}, xs[r * HF + q]);
+    for (int q = 0; q < FPL; ++q) axpy_pair_lds(acc[q], f32x2{wr.x, wr.y}, xs[r * HF + q]);
   }
 #pragma unroll
   for (int q = 0; q < FPL; ++q) { acc1[q] = acc[q].x; acc2[q] = acc[q].y; }

@@ -130,14 +130,25 @@ __device__ __forceinline__ void axpy_pair(f32x2& a, const f32x2 w, const float x
   const f32x2 p = w * xx;
   a = a + p;
 }
-// The same two roundings as two scalar chains.  For sums whose x comes out of LDS one float at a time (chain_rows): there the
-// packed form compiles to `v_pk_mul_f32 v[w:w+1], v[x:x+1] op_sel_hi:[1,0]` with an UNDEFINED high register, and the H = 64 wave
-// kernel — all 64 lanes summing — returned wrong sums in lanes 48..63 of the .x half about once in a hundred batches whenever
-// another kernel (a scoring loop's heads on a second stream) ran beside it: DESIGN.md §6, tools/dbg_two_stream.py.  In-kernel
-// check: the scalar form never, 0 of 3 000 batches.
-__device__ __forceinline__ void axpy_pair_scalar(f32x2& a, const f32x2 w, const float x) {
+// The same for sums whose x comes out of LDS one float at a time (chain_rows).  There the form above compiles to
+// `v_pk_mul_f32 v[w:w+1], v[x:x+1] op_sel_hi:[1,0]` — the pair's high register is never written, the instruction only names it — and
+// the H = 64 wave kernel (all 64 lanes summing) returned wrong .x sums in lanes 48..63 about once in a hundred batches whenever
+// another kernel ran beside it (a scoring loop's heads on a second stream): DESIGN.md section 6, tools/loop_race_check.py.  With both
+// halves of the pair real registers (one v_mov per entry) the in-kernel check (-DOCN_X_WAVE_CHECK) found 0 disagreements in 3 600
+// batches where the form above had ~50; two scalar chains are as clean and 5 % slower on the ppa / citation2 steps.
+__device__ __forceinline__ void axpy_pair_lds(f32x2& a, const f32x2 w, const float x) {
+#if defined(OCN_X_PACKED_CHAIN)     /* A/B builds only (tools/ab_flags.sh): the form that failed ... */
+  axpy_pair(a, w, x);
+#elif defined(OCN_X_SCALAR_CHAIN)   /* ... and two scalar chains */
   a[0] = __fadd_rn(a[0], __fmul_rn(w[0], x));
   a[1] = __fadd_rn(a[1], __fmul_rn(w[1], x));
+#else
+#pragma clang fp contract(off)
+  f32x2 xx = {x, x};
+  asm volatile("" : "+v"(xx));
+  const f32x2 p = w * xx;
+  a = a + p;
+#endif
 }
 
 __device__ __forceinline__ void axpy4(float4& acc, float w, const float4& x) {
