@@ -21,7 +21,7 @@ from ocn_amd.model import predictor_dict
 from ocn_amd.pipeline import overlapped_steps
 from ocn_amd.utils import adjoverlap
 DEV = torch.device("cuda:0")
-n, avg, mx, B, seed, iso = 20000, 10, 600, int(os.environ.get('DBG_B', '8192')), 3, 100
+n, avg, mx, B, seed, iso = int(os.environ.get('DBG_N', '20000')), 10, 600, int(os.environ.get('DBG_B', '8192')), 3, 100
 oadj = make_graph(n, avg, mx, seed, isolated=iso)
 e0 = batch(oadj, B, seed + 50)
 adj = to_product(oadj, DEV)
@@ -30,12 +30,18 @@ adj2.nnz()
 H = int(os.environ.get("DBG_H", "64"))
 torch.manual_seed(seed + 5)
 x = torch.randn(n, H, device=DEV)
-pred = predictor_dict["cn5"](H, H, 1, 3, 0.0, 0.0, True).to(DEV).eval()
-pred.innerprod.fill_(0.37)
+name = os.environ.get("DBG_PRED", "cn5")
+pred = predictor_dict[name](H, H, 1, 3, 0.0, 0.0, True).to(DEV).eval()
+if name == "cn5":
+    pred.innerprod.fill_(float(os.environ.get("DBG_IP", "0.37")))
 args = SimpleNamespace(sum=0.7)
 g = torch.Generator().manual_seed(9)
 batches = [e0.to(DEV)[:, torch.randperm(B, generator=g).to(DEV)][:, : max(B - 5 * q, 1)].contiguous() for q in range(12)]
+route = os.environ.get("DBG_ROUTE", "pattern")            # pattern: adjoverlap on A and A.A; walk: the pygho route (get_cn1_cn2)
 def handles(e):
+    if route == "walk":
+        from ocn_amd.utils import get_cn1_cn2
+        return get_cn1_cn2(adj, e)
     return adjoverlap(adj, adj, e), adjoverlap(adj, adj2, e)
 def begin(it):
     return pred.begin(x, adj, *handles(batches[it]), batches[it], slot=it, args=args if it % 2 else None)
@@ -64,10 +70,11 @@ with torch.no_grad():
             return torch.cat([pl.reshape(-1), y.reshape(-1)])
         return pred.finish(x, tok, args)
     dummy_a = torch.randn(8192, 256, device=DEV); dummy_b = torch.randn(256, 256, device=DEV); dummy_c = torch.empty(8192, 256, device=DEV)
+    loop_batch = int(os.environ['DBG_LOOP_BATCH']) if os.environ.get('DBG_LOOP_BATCH') else None     # what the loop takes its depth from (ops.loop_depth)
     live = []
     def run(overlap):
         live.clear()
-        return [o.clone() for o in overlapped_steps(begin, fin, len(batches), overlap=overlap, batch=None)]
+        return [o.clone() for o in overlapped_steps(begin, fin, len(batches), overlap=overlap, batch=loop_batch)]
     base = run(False)
     torch.cuda.synchronize()
     base2 = run(False)
