@@ -384,6 +384,9 @@ int ocn_spgemm_pattern_fill(const int64_t* rowptrA, const int32_t* colA, int64_t
  * latter are ignored); `done` (int32 [n_rows], zero before the first call, kept by the caller between calls) marks the rows that
  * exist, a row is built by the request that turns its word from 0 to 1.  Rows never requested stay unwritten.  ocn_cn_flags
  * takes such a T2 with rowptrT2 == NULL (n_cols > 8192 only: small graphs read the row lengths too). */
+/* Up to this many columns ocn_cn_flags keeps a workgroup's column histogram in LDS and reads T2's row lengths beside its bit rows
+ * (so T2 must come with its row pointers there). */
+int32_t ocn_cn_flags_small_graph_cols(void);
 int ocn_spgemm_bit_rows(const int64_t* rowptrA, const int32_t* colA, int64_t n_rows, const int64_t* rowptrB, const int32_t* colB,
                         int64_t n_colsB, const int64_t* rows, int64_t n_req, int32_t* done, uint32_t* bitmap,
                         int64_t bm_stride_words, void* stream);

@@ -40,6 +40,7 @@ SIGNATURES = {
                                     _P, _P]),
     "ocn_neighbor_degree_sum": (c_int32, [_P, _P, c_int64, _P, _P]),
     "ocn_walk_prep_max_batch": (c_int32, []),
+    "ocn_cn_flags_small_graph_cols": (c_int32, []),
     "ocn_walk_prep": (c_int32, [_P, _P, _P, _P, c_int64, c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ocn_cn_walk_group": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "ocn_walk_rev_offsets": (c_int32, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P]),

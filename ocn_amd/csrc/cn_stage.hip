@@ -1680,6 +1680,8 @@ static void launch_gather(const int64_t* rowptrA, const int32_t* colA, const int
 
 extern "C" {
 
+int32_t ocn_cn_flags_small_graph_cols(void) { return LH_MAX_COLS; }
+
 int ocn_cn_flags(const int64_t* rowptrA, const int32_t* colA, const int64_t* rowptrT1,
                  const int32_t* colT1, const int64_t* rowptrT2, const int32_t* colT2,
                  const uint32_t* bitmapT1, int64_t bm1_stride_words, const uint32_t* bitmapT2, int64_t bm_stride_words,

@@ -256,7 +256,7 @@ def cn_flags(rowptrA: Tensor, colA: Tensor, t1: Optional[Tuple[Tensor, Tensor]],
     if not walk:
         _req(t1[0], torch.int64, "rowptrT1", 1); _req(t1[1], torch.int32, "colT1", 1)
         if t2 is not None:
-            if t2[0] is not None or t2_bitmap is None or n_cols <= LH_MAX_COLS:      # (a product with rows on demand: bit rows only)
+            if t2[0] is not None or t2_bitmap is None or n_cols <= small_graph_cols():      # (a product with rows on demand: bit rows only)
                 _req(t2[0], torch.int64, "rowptrT2", 1)
             if t2[1] is not None or t2_bitmap is None:           # (with bit rows the kernel never reads T2's column ids: they may be deferred)
                 _req(t2[1], torch.int32, "colT2", 1)
@@ -716,7 +716,12 @@ def spgemm_pattern(rowptrA, colA, rowptrB, colB, n_cols_b: int, defer_fill: bool
     return rowptrC, fill(), bitmap
 
 
-LH_MAX_COLS = 8192                # cn_stage.hip: up to this many columns the intersection pass reads T2's row lengths beside its bit rows
+def small_graph_cols() -> int:
+    """ocn_hip.h: ocn_cn_flags_small_graph_cols — up to this many columns the intersection pass reads T2's row lengths beside its
+    bit rows (so a product whose rows are built on demand is not for such graphs)."""
+    return int(_lib.lib().ocn_cn_flags_small_graph_cols())
+
+
 lazy_product_rows = os.environ.get("OCN_LAZY_PRODUCT", "1") != "0"     # a product formed under autograd builds its bit rows on demand (sparse._lazy_product)
 
 

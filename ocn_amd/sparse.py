@@ -478,7 +478,7 @@ class CooView:
         if a._sizes[1] != b._sizes[0]:
             raise ValueError("shape mismatch in sparse @ sparse")
         n, m = a._sizes[0], b._sizes[1]
-        if (ops.lazy_product_rows and torch.is_grad_enabled() and a._rowptr.is_cuda and m > ops.LH_MAX_COLS
+        if (ops.lazy_product_rows and torch.is_grad_enabled() and a._rowptr.is_cuda and m > ops.small_graph_cols()
                 and 0 < n * ((m + 31) // 32) * 4 <= ops.a2_bitmap_max_bytes and m <= ops.spgemm_max_cols()):
             return CooView(SparseTensor._lazy_product(a, b), is_product=True)
         rowptr, col, bitmap = ops.spgemm_pattern(a._rowptr, a._col, b._rowptr, b._col, b._sizes[1], defer_fill=True)
