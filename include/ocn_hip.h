@@ -515,7 +515,8 @@ int ocn_heads_fused(const OcnHeadsArgs* args, void* stream);
 /* Batches of up to `max_rows` candidates are scored by the small-batch form of the same head — 32 candidates per workgroup,
  * the four waves splitting every layer's output features — which returns the same bits as the throughput form at a fifth of
  * its latency (Cora's 1 152-candidate batch: nine 128-row tiles = 70 us whatever the batch size).  Sets the bound (process-wide;
- * default 16384 = two rounds of workgroups on 256 CUs) and returns the previous one; a negative argument only queries. */
+ * default 16384 = two rounds of workgroups on 256 CUs; quoted at H = 256 — at H = 128 twice as many rows take the small form) and
+ * returns the previous one; a negative argument only queries. */
 int64_t ocn_heads_small_batch(int64_t max_rows);
 
 /* Training-side pieces (NeighborOverlap_large.py:56-63, 76-90).
