@@ -15,17 +15,21 @@ import torch
 if flags:
     from ocn_amd import _lib
     _lib.build(force=True, extra_flags=flags, out="/tmp/libocn_dbg.so")
-from tests.helpers import batch, make_graph, to_product, product_adj2
+from ocn_amd.sparse import SparseTensor
+from ocn_amd.synth import chung_lu_graph, sample_edges
 from ocn_amd import ops
 from ocn_amd.model import predictor_dict
 from ocn_amd.pipeline import overlapped_steps
 from ocn_amd.utils import adjoverlap
 DEV = torch.device("cuda:0")
 n, avg, mx, B, seed, iso = int(os.environ.get('DBG_N', '20000')), 10, 600, int(os.environ.get('DBG_B', '8192')), 3, 100
-oadj = make_graph(n, avg, mx, seed, isolated=iso)
-e0 = batch(oadj, B, seed + 50)
-adj = to_product(oadj, DEV)
-adj2 = product_adj2(adj)
+ei = chung_lu_graph(n - iso, avg_deg=avg, max_deg=min(mx, n - iso - 1), seed=seed, clique_frac=0.5)       # the last `iso` nodes keep degree 0
+adj = SparseTensor.from_edge_index(ei.to(DEV), sparse_sizes=(n, n)).to_symmetric()
+r_, c_, _ = adj.coo()
+e0 = sample_edges(r_.cpu(), c_.cpu(), n, B, seed=seed + 50)
+with torch.no_grad():
+    sp_ = adj.to_torch_sparse_coo_tensor()
+    adj2 = SparseTensor.from_torch_sparse_coo_tensor(sp_ @ sp_, False)
 adj2.nnz()
 H = int(os.environ.get("DBG_H", "64"))
 torch.manual_seed(seed + 5)
