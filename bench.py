@@ -178,8 +178,9 @@ def build_workload(args, dev, rank, world):
         if cfg["route"] == "block":
             adj2 = sparse_tensor_multiply(adj, 1024)
         else:
-            sp = adj.to_torch_sparse_coo_tensor()
-            adj2 = SparseTensor.from_torch_sparse_coo_tensor(sp @ sp, False)
+            with torch.no_grad():                         # (the drivers' test() is @torch.no_grad(): the whole product, not the training step's rows on demand)
+                sp = adj.to_torch_sparse_coo_tensor()
+                adj2 = SparseTensor.from_torch_sparse_coo_tensor(sp @ sp, False)
         torch.cuda.synchronize()
         t_a2 = time.time() - t0
     r, c, _ = adj.coo()
