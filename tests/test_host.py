@@ -215,6 +215,13 @@ def test_adjoverlap_signature_and_unsupported_branches():
         adjoverlap(adj, adj, torch.tensor([[0], [1]]), calresadj=True)
 
 
+def test_library_knobs_have_their_documented_defaults(hiplib):
+    """Host-only entries: the bound of the small-batch head (include/ocn_hip.h) and the small-graph bound of the intersection pass."""
+    assert hiplib.ocn_heads_small_batch(-1) == 16384
+    assert hiplib.ocn_heads_small_batch(100) == 16384 and hiplib.ocn_heads_small_batch(16384) == 100
+    assert hiplib.ocn_cn_flags_small_graph_cols() == 8192
+
+
 def test_heads_kernel_isa_audit():
     """The fused heads' k-step is hand-placed inline asm whose waits are counted by hand, and the small-batch form requests its
     weight fragments by asm and waits for them by count (heads.hip).  tools/check_heads_asm.py compiles both and checks the ISA: no instruction touches the destination of an LDS read the lgkmcnt ladder has not
