@@ -166,6 +166,114 @@ __global__ __launch_bounds__(OCN_BLOCK) void colsum_short_kernel(
   }
 }
 
+// Columns with 65 .. CS_MED_MAX entries: ONE WAVE each, four columns per workgroup, no workgroup barrier.  At the collab shape a
+// trained model's 65 536-edge batch has ~3 000 such columns and none longer (the longest: ~400 entries); a whole workgroup per column
+// (colsum_long_kernel: ticket, bucket sort with five barriers, staged values, wave 0's chain while three waves wait) spent ~20 us of
+// latencies on each.  Here the wave ranks its keys against all the column's keys read back from LDS (positions are distinct: rank = number of smaller
+// keys), scatters them into rank order, stages the values in that order and runs the same lane chain.
+// Longer columns go on to long2_list for colsum_long_kernel.
+#define CS_MED_MAX 512
+#define CS_MED_KPL (CS_MED_MAX / OCN_WAVE)      /* keys per lane */
+template <int NR>
+__device__ __forceinline__ void med_rank(int (&rank)[CS_MED_KPL], const uint32_t (&key)[CS_MED_KPL], const uint32_t* keys, int n) {
+  for (int m0 = 0; m0 < n; m0 += 8) {
+    uint32_t km[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) km[u] = keys[m0 + u];                     // (past n: 0xffffffff, smaller than no key)
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) rank[j] += km[u] < key[j];
+  }
+}
+
+__global__ __launch_bounds__(OCN_BLOCK) void colsum_medium_kernel(
+    const u64* __restrict__ hist, const i64* __restrict__ col_off, const uint32_t* __restrict__ entries,
+    ColCtx cx, const float* __restrict__ innerprod, const int32_t* __restrict__ scalars,
+    float* __restrict__ s2, float* __restrict__ s3, const int32_t* __restrict__ long_list, const int32_t* __restrict__ n_long,
+    int32_t* __restrict__ long2_list, int32_t* __restrict__ n_long2, const float* __restrict__ s2_init) {
+  __shared__ uint32_t s_key[OCN_WPB][CS_MED_MAX];      // the column's entry positions as loaded (padded with 0xffffffff) ...
+  __shared__ uint32_t s_srt[OCN_WPB][CS_MED_MAX];      // ... and in rank order
+  __shared__ float s_val[OCN_WPB][CS_MED_MAX];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  cx.nip = cn5_nip(scalars[0], innerprod[0]);
+  const int total = n_long[0];
+  for (int item = blockIdx.x * OCN_WPB + w; item < total; item += gridDim.x * OCN_WPB) {
+    const i64 c = long_list[item];
+    const i64 b = col_off[c];
+    const int n = (int)(col_off[c + 1] - b);
+    if (n > CS_MED_MAX) {
+      if (lane == 0) long2_list[atomicAdd(n_long2, 1)] = (int32_t)c;
+      continue;
+    }
+    uint32_t key[CS_MED_KPL];
+#pragma unroll
+    for (int j = 0; j < CS_MED_KPL; ++j) {
+      const int q = lane + OCN_WAVE * j;
+      key[j] = q < n ? entries[b + q] : 0xffffffffu;
+      s_key[w][q] = key[j];                              // (the whole array: the ranking loop below reads it in blocks of eight)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // rank = the number of smaller keys (positions are distinct).  Key m is a broadcast LDS read; eight of them are requested before
+    // the first is compared — one read per step put the LDS latency on every step (66 us for the ~3 000 columns of the collab batch;
+    // a bitonic network on the wave's array: 84 us, broadcasting out of registers with v_readlane: 96 us).
+    int rank[CS_MED_KPL];
+#pragma unroll
+    for (int j = 0; j < CS_MED_KPL; ++j) rank[j] = 0;
+    // (only the registers that hold keys take part: a column of 100 entries fills two of the eight)
+    if (n <= 2 * OCN_WAVE) med_rank<2>(rank, key, &s_key[w][0], n);
+    else if (n <= 4 * OCN_WAVE) med_rank<4>(rank, key, &s_key[w][0], n);
+    else med_rank<CS_MED_KPL>(rank, key, &s_key[w][0], n);
+#pragma unroll
+    for (int j = 0; j < CS_MED_KPL; ++j)
+      if (lane + OCN_WAVE * j < n) s_srt[w][rank[j]] = key[j];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const float t = col_t(hist, c, cx.nip);
+    // the entries' flag bytes (and walk counts) in rank order: ALL requested at once — one byte per entry from all over the flag
+    // buffer, up to eight trips to memory if each waited for the one before
+    unsigned fa[CS_MED_KPL], fb[CS_MED_KPL];
+    float cw[CS_MED_KPL];
+#pragma unroll
+    for (int j = 0; j < CS_MED_KPL; ++j) {
+      const int q = lane + OCN_WAVE * j;
+      const uint32_t p = q < n ? s_srt[w][q] : 0u;
+      fa[j] = q < n ? cx.flagsA[p] : 0u;
+      fb[j] = (q < n && cx.flagsB) ? cx.flagsB[p] : 0u;
+      cw[j] = (q < n && cx.wc) ? (float)cx.wc[p] : 1.0f;
+    }
+    float inv2 = 0.0f;
+    for (int pass = 0; pass < (s3 ? 2 : 1); ++pass) {
+#pragma unroll
+      for (int j = 0; j < CS_MED_KPL; ++j) {
+        const int q = lane + OCN_WAVE * j;
+        if (q < n) {                                     // entry_v2's arithmetic on the bytes fetched above
+          const float cc = (fa[j] & OCN_F_CN2) ? cw[j] : 0.0f;
+          const float tt = (fa[j] & OCN_F_CN1) ? t : 0.0f;
+          const bool in2 = fa[j] != 0;
+          const float a3 = (fb[j] & OCN_F_CN1) ? 1.0f : 0.0f;
+          const float v2 = __fsub_rn(cc, tt);
+          float v = in2 ? v2 : 0.0f;
+          if (pass) v = __fsub_rn(__fsub_rn(a3, tt), __fmul_rn(cx.nip, in2 ? __fmul_rn(v2, inv2) : 0.0f));
+          s_val[w][q] = v;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      float acc = (pass == 0 && s2_init) ? s2_init[c] : 0.0f;
+      for (int r0 = 0; r0 < n; r0 += OCN_WAVE) {
+        const float v = r0 + lane < n ? s_val[w][r0 + lane] : 0.0f;
+        acc = chain_add(acc, v, n - r0 < OCN_WAVE ? n - r0 : OCN_WAVE);
+      }
+      if (pass == 0) {
+        if (lane == 0) s2[c] = acc;
+        inv2 = 1.0f / (acc == 0.0f ? 1.0f : acc);
+      } else if (lane == 0) {
+        s3[c] = acc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+}
+
 // In-place sort of a[0..n) (LDS or global), any n: the bitonic network in its all-ascending form (first step of
 // a merge mirrors, the rest are strides; every compare-exchange leaves the minimum at the lower index), so
 // partners beyond n behave as +inf and are simply skipped.
@@ -210,7 +318,7 @@ __global__ __launch_bounds__(OCN_BLOCK) void colsum_long_kernel(
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   cx.nip = cn5_nip(scalars[0], innerprod[0]);
   const int total = n_long[0];
-  for (;;) {
+  for (;;) {                                             // (items dealt round robin instead of ticket-drawn: 231 against 207 µs, round 4)
     if (threadIdx.x == 0) s_item = atomicAdd(ticket, 1);
     __syncthreads();
     const int item = s_item;
@@ -301,9 +409,9 @@ __global__ __launch_bounds__(OCN_BLOCK) void colsum_long_kernel(
 extern "C" {
 
 int64_t ocn_cn_colsum_workspace_bytes(int64_t N, int64_t flags_cap) {
-  // col_off int64[N+1] | counts/cursor int32[N] | long_list int32[N] | tickets int32[4] | scan state | entries uint32[cap]
+  // col_off int64[N+1] | counts/cursor int32[N] | long_list int32[N] | tickets int32[4] | scan state | entries uint32[cap] | long2_list int32[N]
   const int64_t a = ((N + 1) * 8 + 15) / 16 * 16, b = (N * 4 + 15) / 16 * 16;
-  return a + 2 * b + 16 + (ocn_scan_workspace_bytes(N) + 15) / 16 * 16 + (flags_cap * 4 + 15) / 16 * 16 + 64;
+  return a + 2 * b + 16 + (ocn_scan_workspace_bytes(N) + 15) / 16 * 16 + (flags_cap * 4 + 15) / 16 * 16 + b + 64;
 }
 
 int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64_t* src, int64_t B,
@@ -321,10 +429,11 @@ int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64
   i64* col_off = (i64*)ws;
   int32_t* counts = (int32_t*)(ws + a);
   int32_t* long_list = (int32_t*)(ws + a + b);
-  int32_t* tickets = (int32_t*)(ws + a + 2 * b);                    // [0] number of long columns, [1] work ticket
+  int32_t* tickets = (int32_t*)(ws + a + 2 * b);                    // [0] columns longer than a wave's 64, [1] work ticket of the long kernel, [2] columns longer than CS_MED_MAX
   void* scan_ws = (void*)(ws + a + 2 * b + 16);
   const int64_t sw = (ocn_scan_workspace_bytes(N) + 15) / 16 * 16;
   uint32_t* entries = (uint32_t*)(ws + a + 2 * b + 16 + sw);
+  int32_t* long2_list = (int32_t*)(ws + a + 2 * b + 16 + sw + (flags_cap * 4 + 15) / 16 * 16);
   const int gridN = grid_for((N + OCN_BLOCK - 1) / OCN_BLOCK, 2048);
   const int gridB = grid_for((B + OCN_WPB - 1) / OCN_WPB, 1 << 16);
   int rc = ocn_cn5_column_stats(hist, N, scalars, stream);           // nip needs the batch's scale (idempotent)
@@ -357,9 +466,12 @@ int ocn_cn_colsum_exact(const int64_t* rowptrA, const int32_t* colA, const int64
   hipLaunchKernelGGL(colsum_short_kernel, dim3(grid_for((N + OCN_WPB - 1) / OCN_WPB, 1 << 15)), dim3(OCN_BLOCK), 0, st,
                      (const u64*)hist, (i64)N, (const i64*)col_off, (const uint32_t*)entries, cx, innerprod,
                      (const int32_t*)scalars, s2, s3, long_list, tickets, s2_init);
+  hipLaunchKernelGGL(colsum_medium_kernel, dim3(256 * 4), dim3(OCN_BLOCK), 0, st, (const u64*)hist, (const i64*)col_off,
+                     (const uint32_t*)entries, cx, innerprod, (const int32_t*)scalars, s2, s3, (const int32_t*)long_list,
+                     (const int32_t*)tickets, long2_list, tickets + 2, s2_init);
   hipLaunchKernelGGL(colsum_long_kernel, dim3(256 * 3), dim3(OCN_BLOCK), 0, st, (const u64*)hist, (const i64*)col_off,
-                     entries, cx, innerprod, (const int32_t*)scalars, s2, s3, (const int32_t*)long_list,
-                     (const int32_t*)tickets, tickets + 1, s2_init, (i64)(flags_cap > 0 ? flags_cap : 1));
+                     entries, cx, innerprod, (const int32_t*)scalars, s2, s3, (const int32_t*)long2_list,
+                     (const int32_t*)(tickets + 2), tickets + 1, s2_init, (i64)(flags_cap > 0 ? flags_cap : 1));
   return launch_status();
 }
 
